@@ -1,0 +1,221 @@
+/* liboige_hip.so -- C ABI of the MI355X (gfx950) per-step task math.
+ *
+ * The reference (OmniIsaacGymEnvs, 100 % Python) has no FFI; the "operator API" this
+ * library sits behind is the RLTask method contract that VecEnvRLGames.step drives
+ * (/root/reference/omniisaacgymenvs/envs/vec_env_rlgames.py:79,92 and
+ * tasks/base/rl_task.py:278-298).  Each entry point below names the reference method(s)
+ * whose arithmetic it replaces.  omniisaacgymenvs_amd/_lib.py is the ctypes binding the
+ * Python task classes call through.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to a contiguous row-major buffer owned by the caller
+ *    (torch tensor .data_ptr()); the library never allocates or frees tensor memory;
+ *  - floats are fp32; flags and counters are int64 (rl_task.py:165-166); quaternions wxyz;
+ *  - calls are asynchronous launches on `stream` (a hipStream_t; NULL = default stream) and
+ *    perform no host synchronisation;
+ *  - return 0 on success, a negative OIGE_E* code otherwise; oige_last_error() gives the
+ *    message for the calling thread.  Nothing throws across the ABI.
+ */
+#ifndef OIGE_HIP_H
+#define OIGE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OIGE_ABI_VERSION 1
+#define OIGE_MAX_DOF 32
+#define OIGE_TILE_ENVS 64 /* one wavefront = one tile of envs; granularity of tile_reset_counts */
+
+#define OIGE_OK 0
+#define OIGE_EINVAL (-1)  /* bad argument (null pointer, size, alignment, unsupported D/S) */
+#define OIGE_ELAUNCH (-2) /* HIP launch error */
+
+typedef void* oige_stream_t; /* hipStream_t */
+
+const char* oige_last_error(void);
+int oige_version(void);
+
+/* ------------------------------------------------------------------ compaction
+ * reset_env_ids = reset_buf.nonzero().squeeze(-1): ascending int64 ids, without the host
+ * sync of len() (tasks/shared/locomotion.py:121-122, cartpole.py:112-113,
+ * in_hand_manipulation.py:318-319, anymal_terrain.py:433, randomize.py:284,315).
+ *
+ * workspace: oige_workspace_ints(n) int32 entries, 16-byte aligned, holding
+ *   [ per-tile counts of non-zero flags (64 envs per tile), padded to whole 256-env groups |
+ *     exclusive prefix per 256-env group, then the total ].
+ * ids_out has capacity n; *count_out (device int64) receives the number of ids.
+ */
+int64_t oige_num_tiles(int64_t n);
+int64_t oige_workspace_ints(int64_t n);
+int oige_count_flags_i64(const int64_t* flags, int64_t n, int32_t* workspace, oige_stream_t stream);
+int oige_compact_i64(const int64_t* flags, int64_t n, int32_t* workspace, int64_t* ids_out,
+                     int64_t* count_out, oige_stream_t stream);
+
+/* ------------------------------------------------------------------ locomotion (Ant, Humanoid)
+ * Scalars: LocomotionTask.update_config (tasks/shared/locomotion.py:50-65) and
+ * post_reset (:162-184); tables: tasks/ant.py:89-93, tasks/humanoid.py:91-121.
+ * The per-env-constant (N,k) tensors of the reference (targets, inv_start_rot,
+ * basis_vec0/1, locomotion.py:168-177) are passed once as scalars.                      */
+typedef struct oige_locomotion_params {
+  int32_t num_dof;         /* D */
+  int32_t num_sensors;     /* S */
+  int32_t limit_cost_kind; /* 0: Ant, ant.py:107-109; 1: Humanoid, humanoid.py:135-141 */
+  int32_t reserved0;
+  float dt;                /* 1/60, locomotion.py:178 */
+  float dof_vel_scale;
+  float contact_force_scale;
+  float angular_velocity_scale;
+  float heading_weight;
+  float up_weight;
+  float actions_cost_scale;
+  float energy_cost_scale;
+  float joints_at_limit_cost_scale;
+  float death_cost;
+  float termination_height;
+  float alive_reward_scale;
+  float max_episode_length; /* compared as float: is_done(..., max_episode_length: float) */
+  float power_scale;
+  float clip_actions;       /* used only when OIGE_PRE_CLAMP_ACTIONS is set */
+  float reserved1;
+  float target[3];
+  float inv_start_rot[4];
+  float basis_vec0[3];
+  float basis_vec1[3];
+  float reserved2[3];
+  float dof_limits_lower[OIGE_MAX_DOF];
+  float dof_limits_upper[OIGE_MAX_DOF];
+  float joint_gears[OIGE_MAX_DOF];
+  float motor_effort_ratio[OIGE_MAX_DOF];
+} oige_locomotion_params;
+
+/* What the ArticulationView getters return (locomotion.py:76-84); read-only. */
+typedef struct oige_locomotion_state {
+  const float* torso_position;       /* (N,3) world */
+  const float* torso_rotation;       /* (N,4) wxyz  */
+  const float* velocities;           /* (N,6) lin, ang */
+  const float* dof_pos;              /* (N,D) */
+  const float* dof_vel;              /* (N,D) */
+  const float* sensor_force_torques; /* (N,S,6) */
+} oige_locomotion_state;
+
+/* RLTask buffers (rl_task.py:162-166) + LocomotionTask state (locomotion.py:169-184). */
+typedef struct oige_locomotion_buffers {
+  float* obs_buf;          /* (N, 12+3D+6S) */
+  float* rew_buf;          /* (N,) */
+  int64_t* reset_buf;      /* (N,) */
+  int64_t* progress_buf;   /* (N,) */
+  float* potentials;       /* (N,) */
+  float* prev_potentials;  /* (N,) */
+  float* up_vec;           /* (N,3) or NULL (written back as locomotion.py:90) */
+  float* heading_vec;      /* (N,3) or NULL (locomotion.py:91) */
+  const float* actions;    /* (N,D) the task's self.actions */
+  int32_t* reset_workspace; /* oige_workspace_ints(N) int32, zero-initialised once by the caller,
+                               16-byte aligned.  The DONE stage leaves the per-tile counts of
+                               non-zero reset flags here for the next pre_physics (may be NULL for
+                               post_physics; required by pre_physics) */
+} oige_locomotion_buffers;
+
+/* stages of RLTask.post_physics_step (rl_task.py:289-295), any subset, executed in this order */
+#define OIGE_STAGE_PROGRESS 1u /* progress_buf[:] += 1                      rl_task.py:289 */
+#define OIGE_STAGE_OBS 2u      /* get_observations      locomotion.py:75-115, jit :225-284 */
+#define OIGE_STAGE_METRICS 4u  /* calculate_metrics     locomotion.py:190-206, jit :296-345,
+                                  + get_dof_at_limit_cost ant.py:107 / humanoid.py:135      */
+#define OIGE_STAGE_DONE 8u     /* is_done               locomotion.py:208-211, jit :288-292 */
+#define OIGE_STAGE_ALL 15u
+
+int oige_locomotion_post_physics(const oige_locomotion_params* params, const oige_locomotion_state* state,
+                                 const oige_locomotion_buffers* buffers, int64_t num_envs, uint32_t stages,
+                                 oige_stream_t stream);
+
+/* reset_idx inputs/outputs (locomotion.py:133-158).  Outputs are the compacted rows the view
+ * setters take (set_joint_positions/velocities, set_world_poses, set_velocities with
+ * indices=env_ids), in ascending env order; capacity N rows each.                          */
+typedef struct oige_locomotion_reset_io {
+  const float* initial_root_pos; /* (N,3) */
+  const float* initial_root_rot; /* (N,4) */
+  const float* initial_dof_pos;  /* (N,D) */
+  const float* u_pos;            /* NULL, or (n,D) pre-drawn U[0,1): 1st draw, locomotion.py:137 */
+  const float* u_vel;            /* NULL, or (n,D) pre-drawn U[0,1): 2nd draw, locomotion.py:139 */
+  uint64_t seed;                 /* in-kernel Philox4x32-10 key when u_pos/u_vel are NULL */
+  uint64_t step;                 /* mixed into the Philox counter */
+  int64_t* env_ids;              /* out (N,)  ascending ids == reset_buf.nonzero().squeeze(-1) */
+  int64_t* count;                /* out device scalar: number of ids */
+  float* dof_pos_out;            /* out (n,D) */
+  float* dof_vel_out;            /* out (n,D) */
+  float* root_pos_out;           /* out (n,3) */
+  float* root_rot_out;           /* out (n,4) */
+  float* root_vel_out;           /* out (n,6) zeros */
+} oige_locomotion_reset_io;
+
+#define OIGE_PRE_CLAMP_ACTIONS 1u /* fold VecEnvRLGames' torch.clamp(actions, +-clip) (vec_env_rlgames.py:77) */
+#define OIGE_PRE_COUNTS_VALID 2u  /* reset_workspace tile counts already match reset_buf (skip recount) */
+
+/* LocomotionTask.pre_physics_step (locomotion.py:117-131): compaction of reset_buf, reset_idx of
+ * the flagged envs, actions clone, forces = actions * joint_gears * power_scale.
+ * actions_out may be NULL (no clone) or alias actions_in.                                   */
+int oige_locomotion_pre_physics(const oige_locomotion_params* params, const float* actions_in,
+                                const oige_locomotion_buffers* buffers, const oige_locomotion_reset_io* reset_io,
+                                float* actions_out, float* forces_out, int64_t num_envs, uint32_t flags,
+                                oige_stream_t stream);
+
+/* LocomotionTask.reset_idx(env_ids) with caller-provided ids (locomotion.py:133-158; used by
+ * post_reset :187-188).  reset_io->env_ids / ->count are INPUTS here (count: device scalar).     */
+int oige_locomotion_reset_idx(const oige_locomotion_params* params, const oige_locomotion_buffers* buffers,
+                              const oige_locomotion_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                              oige_stream_t stream);
+
+/* ------------------------------------------------------------------ Cartpole
+ * tasks/cartpole.py:91-164.                                                                 */
+typedef struct oige_cartpole_params {
+  int32_t cart_dof_idx;   /* cartpole.py:147 */
+  int32_t pole_dof_idx;   /* cartpole.py:148 */
+  int32_t num_dof;        /* row width of dof_pos/dof_vel (2) */
+  int32_t reserved0;
+  float reset_dist;       /* Cartpole.yaml:10 */
+  float max_push_effort;  /* Cartpole.yaml:11 */
+  float max_episode_length; /* 500, cartpole.py:44 */
+  float reserved1;
+} oige_cartpole_params;
+
+typedef struct oige_cartpole_buffers {
+  float* obs_buf;         /* (N,4) */
+  float* rew_buf;         /* (N,) */
+  int64_t* reset_buf;     /* (N,) */
+  int64_t* progress_buf;  /* (N,) */
+  int32_t* reset_workspace; /* as oige_locomotion_buffers.reset_workspace */
+} oige_cartpole_buffers;
+
+/* post_physics_step: progress += 1, get_observations (:91-106), calculate_metrics (:153-158),
+ * is_done (:160-164, NOT sticky, >= max_episode_length).  `stages` as for locomotion.       */
+int oige_cartpole_post_physics(const oige_cartpole_params* params, const float* dof_pos, const float* dof_vel,
+                               const oige_cartpole_buffers* buffers, int64_t num_envs, uint32_t stages,
+                               oige_stream_t stream);
+
+typedef struct oige_cartpole_reset_io {
+  const float* u;      /* NULL, or (4,n) pre-drawn U[0,1): rows = the four torch.rand(n) draws in
+                          cartpole.py:129,130,134,135 order */
+  uint64_t seed;
+  uint64_t step;
+  int64_t* env_ids;    /* out (N,) */
+  int64_t* count;      /* out device scalar */
+  float* dof_pos_out;  /* out (n,num_dof) */
+  float* dof_vel_out;  /* out (n,num_dof) */
+} oige_cartpole_reset_io;
+
+/* pre_physics_step (:108-122): compaction, reset_idx (:124-144), forces[:, cart] = max_effort * a[:,0] */
+int oige_cartpole_pre_physics(const oige_cartpole_params* params, const float* actions /* (N,1) */,
+                              const oige_cartpole_buffers* buffers, const oige_cartpole_reset_io* reset_io,
+                              float* forces_out /* (N,num_dof) */, int64_t num_envs, uint32_t flags,
+                              oige_stream_t stream);
+int oige_cartpole_reset_idx(const oige_cartpole_params* params, const oige_cartpole_buffers* buffers,
+                            const oige_cartpole_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                            oige_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OIGE_HIP_H */

@@ -1,0 +1,169 @@
+"""ctypes binding of liboige_hip.so (include/oige_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, the task
+methods raise.  The library is built in-tree by ``python -m omniisaacgymenvs_amd.build``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboige_hip.so")
+
+OIGE_MAX_DOF = 32
+TILE_ENVS = 64
+
+STAGE_PROGRESS, STAGE_OBS, STAGE_METRICS, STAGE_DONE, STAGE_ALL = 1, 2, 4, 8, 15
+PRE_CLAMP_ACTIONS, PRE_COUNTS_VALID = 1, 2
+
+_f = C.c_float
+_fp = C.c_void_p  # device pointers travel as integers
+
+
+class LocomotionParams(C.Structure):
+    _fields_ = [
+        ("num_dof", C.c_int32), ("num_sensors", C.c_int32), ("limit_cost_kind", C.c_int32), ("reserved0", C.c_int32),
+        ("dt", _f), ("dof_vel_scale", _f), ("contact_force_scale", _f), ("angular_velocity_scale", _f),
+        ("heading_weight", _f), ("up_weight", _f), ("actions_cost_scale", _f), ("energy_cost_scale", _f),
+        ("joints_at_limit_cost_scale", _f), ("death_cost", _f), ("termination_height", _f), ("alive_reward_scale", _f),
+        ("max_episode_length", _f), ("power_scale", _f), ("clip_actions", _f), ("reserved1", _f),
+        ("target", _f * 3), ("inv_start_rot", _f * 4), ("basis_vec0", _f * 3), ("basis_vec1", _f * 3),
+        ("reserved2", _f * 3),
+        ("dof_limits_lower", _f * OIGE_MAX_DOF), ("dof_limits_upper", _f * OIGE_MAX_DOF),
+        ("joint_gears", _f * OIGE_MAX_DOF), ("motor_effort_ratio", _f * OIGE_MAX_DOF),
+    ]
+
+
+class LocomotionState(C.Structure):
+    _fields_ = [(n, _fp) for n in ("torso_position", "torso_rotation", "velocities", "dof_pos", "dof_vel", "sensor_force_torques")]
+
+
+class LocomotionBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in (
+        "obs_buf", "rew_buf", "reset_buf", "progress_buf", "potentials", "prev_potentials", "up_vec", "heading_vec",
+        "actions", "reset_workspace")]
+
+
+class LocomotionResetIO(C.Structure):
+    _fields_ = [
+        ("initial_root_pos", _fp), ("initial_root_rot", _fp), ("initial_dof_pos", _fp), ("u_pos", _fp), ("u_vel", _fp),
+        ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("env_ids", _fp), ("count", _fp), ("dof_pos_out", _fp), ("dof_vel_out", _fp),
+        ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp),
+    ]
+
+
+class CartpoleParams(C.Structure):
+    _fields_ = [
+        ("cart_dof_idx", C.c_int32), ("pole_dof_idx", C.c_int32), ("num_dof", C.c_int32), ("reserved0", C.c_int32),
+        ("reset_dist", _f), ("max_push_effort", _f), ("max_episode_length", _f), ("reserved1", _f),
+    ]
+
+
+class CartpoleBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "reset_workspace")]
+
+
+class CartpoleResetIO(C.Structure):
+    _fields_ = [("u", _fp), ("seed", C.c_uint64), ("step", C.c_uint64), ("env_ids", _fp), ("count", _fp),
+                ("dof_pos_out", _fp), ("dof_vel_out", _fp)]
+
+
+# name -> (restype, argtypes); every symbol include/oige_hip.h declares
+_P = C.c_void_p
+SIGNATURES = {
+    "oige_last_error": (C.c_char_p, []),
+    "oige_version": (C.c_int, []),
+    "oige_num_tiles": (C.c_int64, [C.c_int64]),
+    "oige_workspace_ints": (C.c_int64, [C.c_int64]),
+    "oige_count_flags_i64": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "oige_compact_i64": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P]),
+    "oige_locomotion_post_physics": (C.c_int, [C.POINTER(LocomotionParams), C.POINTER(LocomotionState),
+                                               C.POINTER(LocomotionBuffers), C.c_int64, C.c_uint32, _P]),
+    "oige_locomotion_pre_physics": (C.c_int, [C.POINTER(LocomotionParams), _P, C.POINTER(LocomotionBuffers),
+                                              C.POINTER(LocomotionResetIO), _P, _P, C.c_int64, C.c_uint32, _P]),
+    "oige_locomotion_reset_idx": (C.c_int, [C.POINTER(LocomotionParams), C.POINTER(LocomotionBuffers),
+                                            C.POINTER(LocomotionResetIO), C.c_int64, C.c_int64, _P]),
+    "oige_cartpole_post_physics": (C.c_int, [C.POINTER(CartpoleParams), _P, _P, C.POINTER(CartpoleBuffers), C.c_int64,
+                                             C.c_uint32, _P]),
+    "oige_cartpole_pre_physics": (C.c_int, [C.POINTER(CartpoleParams), _P, C.POINTER(CartpoleBuffers),
+                                            C.POINTER(CartpoleResetIO), _P, C.c_int64, C.c_uint32, _P]),
+    "oige_cartpole_reset_idx": (C.c_int, [C.POINTER(CartpoleParams), C.POINTER(CartpoleBuffers),
+                                          C.POINTER(CartpoleResetIO), C.c_int64, C.c_int64, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class OigeError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load liboige_hip.so; raises loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OigeError(
+            f"{LIB_PATH} is missing: build it with `python -m omniisaacgymenvs_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.oige_version() != 1:
+        raise OigeError(f"liboige_hip.so ABI version {lib.oige_version()} != 1; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().oige_last_error()
+        raise OigeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """data_ptr of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise OigeError("liboige_hip needs contiguous row-major tensors")
+    return t.data_ptr()
+
+
+def require_device_tensor(t: torch.Tensor, dtype: torch.dtype, shape, name: str) -> None:
+    if t.dtype != dtype or tuple(t.shape) != tuple(shape) or not t.is_contiguous():
+        raise OigeError(
+            f"{name}: expected contiguous {dtype} tensor of shape {tuple(shape)}, got {t.dtype} {tuple(t.shape)} "
+            f"contiguous={t.is_contiguous()}"
+        )
+    if t.device.type != "cuda":
+        raise OigeError(f"{name}: liboige_hip kernels need a ROCm device tensor, got device {t.device} (no CPU fallback)")
+
+
+def current_stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def workspace_ints(n: int) -> int:
+    return int(load().oige_workspace_ints(n))
+
+
+def new_workspace(n: int, device) -> torch.Tensor:
+    """Zero-initialised int32 reset workspace (tile counts + group offsets)."""
+    return torch.zeros(max(workspace_ints(n), 4), dtype=torch.int32, device=device)
+
+
+def compact(flags: torch.Tensor, workspace: torch.Tensor, ids_out: torch.Tensor, count_out: torch.Tensor) -> None:
+    """ids_out[:count] = flags.nonzero().squeeze(-1) without a host sync."""
+    n = flags.shape[0]
+    check(load().oige_compact_i64(ptr(flags), n, ptr(workspace), ptr(ids_out), ptr(count_out),
+                                  current_stream(flags.device)), "oige_compact_i64")

@@ -1,0 +1,556 @@
+// Ant / Humanoid per-step task math for gfx950 (MI355X): hand-written HIP, one wavefront per
+// tile of 64 envs, HBM-bound (no MFMA: ~0.3 flop/B).
+//
+// Replaces, behind the unchanged LocomotionTask method contract, the reference's
+//   post_physics_step  tasks/base/rl_task.py:278-298          (progress += 1, then ...)
+//   get_observations   tasks/shared/locomotion.py:75-115, jit :225-284
+//   calculate_metrics  locomotion.py:190-206, jit :296-345; ant.py:107-109; humanoid.py:135-141
+//   is_done            locomotion.py:208-211, jit :288-292
+//   pre_physics_step   locomotion.py:117-131
+//   reset_idx          locomotion.py:133-158
+//
+// post_physics kernel, per tile (algorithmic HBM bytes per env: Ant 532 (+24 with up/heading
+// vectors), Humanoid 748 (+24)):
+//   A. issue every global load of the tile up front: per-env scalars/rows (pos, rot, vel,
+//      potentials, reset, progress) one env per lane, and the four wide arrays (dof_pos,
+//      dof_vel, sensors, actions) as lane-linear float4 runs (1 KiB per wave-instruction);
+//   B. scale the pass-through runs and scatter them into a (64 x num_obs) LDS obs tile;
+//   C. one env per lane: quaternion/frame math -> obs[0:12] into the tile; unscale dof_pos in
+//      place in the tile; reward and done from the tile row and registers; coalesced scalar
+//      stores of rew/reset/progress/potentials;
+//   D. stream the finished obs tile to HBM as one contiguous run of float4 stores.
+// The obs row never makes an HBM round trip between obs, reward and done.
+#include "oige_common.hpp"
+#include "oige_math.hpp"
+#include "oige_tile.hpp"
+
+namespace oige {
+
+struct LocoPost {
+  oige_locomotion_params p;
+  oige_locomotion_state s;
+  oige_locomotion_buffers b;
+  int64_t n;
+  uint32_t stages;
+  float max_len_minus_1;  // (float)((double)max_episode_length - 1.0): `progress >= max_len - 1`
+};
+
+template <int D>
+__device__ __forceinline__ float limit_cost_ant(const float (&o)[D]) {
+  int cnt = 0;  // ant.py:109: sum(obs > 0.99) -- no abs, int64 count, promoted to fp32 at the subtraction
+#pragma unroll
+  for (int j = 0; j < D; ++j) cnt += o[j] > 0.99f ? 1 : 0;
+  return (float)cnt;
+}
+
+template <int D>
+__device__ __forceinline__ float limit_cost_humanoid(const float (&o)[D], const oige_locomotion_params& p) {
+  float acc = 0.0f;  // humanoid.py:137-140
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const float a = __builtin_fabsf(o[j]);
+    const float scaled = (p.joints_at_limit_cost_scale * (a - 0.98f)) / 0.02f;
+    const float term = ((a > 0.98f ? 1.0f : 0.0f) * scaled) * p.motor_effort_ratio[j];
+    acc = j == 0 ? term : acc + term;
+  }
+  return acc;
+}
+
+// reward + done for one env from its obs row pieces (locomotion.py:314-345, :290-291)
+template <int D, int LIMIT>
+__device__ __forceinline__ float reward_of(const oige_locomotion_params& p, float obs0, float up_proj,
+                                           float heading_proj, const float (&dps)[D], const float (&dvs)[D],
+                                           const float (&act)[D], float pot, float prev_pot) {
+  const float hw = p.heading_weight;
+  const float heading_reward = heading_proj > 0.8f ? hw : (hw * heading_proj) / 0.8f;
+  const float up_reward = up_proj > 0.93f ? (0.0f + p.up_weight) : 0.0f;
+  float actions_cost = 0.0f, electricity_cost = 0.0f;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const float a2 = act[j] * act[j];
+    const float el = __builtin_fabsf(act[j] * dvs[j]) * p.motor_effort_ratio[j];
+    actions_cost = j == 0 ? a2 : actions_cost + a2;
+    electricity_cost = j == 0 ? el : electricity_cost + el;
+  }
+  const float lim = LIMIT == 0 ? limit_cost_ant<D>(dps) : limit_cost_humanoid<D>(dps, p);
+  const float progress_reward = pot - prev_pot;
+  float total = progress_reward + p.alive_reward_scale;
+  total = total + up_reward;
+  total = total + heading_reward;
+  total = total - p.actions_cost_scale * actions_cost;
+  total = total - p.energy_cost_scale * electricity_cost;
+  total = total - lim;
+  return obs0 < p.termination_height ? p.death_cost : total;
+}
+
+template <int D, int S, int LIMIT, bool FULL>
+__device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__ tile, int64_t t, int nv) {
+  constexpr int OBS = 12 + 3 * D + 6 * S;
+  constexpr int C_DPOS = 12, C_DVEL = 12 + D, C_SENS = 12 + 2 * D, C_ACT = 12 + 2 * D + 6 * S;
+  const oige_locomotion_params& p = a.p;
+  const int lane = lane_id();
+  const int64_t env0 = t * TILE;
+  const int64_t env = env0 + lane;
+  const bool live = FULL || lane < nv;
+  const bool do_progress = a.stages & OIGE_STAGE_PROGRESS;
+  const bool do_metrics = a.stages & OIGE_STAGE_METRICS;
+  const bool do_done = a.stages & OIGE_STAGE_DONE;
+
+  // ---- A: all loads in flight
+  Chunk<D> c_dpos, c_dvel, c_act;
+  Chunk<6 * S> c_sens;
+  load_chunk<D, FULL>(c_dpos, a.s.dof_pos + env0 * D, nv * D);
+  load_chunk<D, FULL>(c_dvel, a.s.dof_vel + env0 * D, nv * D);
+  load_chunk<6 * S, FULL>(c_sens, a.s.sensor_force_torques + env0 * (6 * S), nv * 6 * S);
+  load_chunk<D, FULL>(c_act, a.b.actions + env0 * D, nv * D);
+
+  f3 pos{0.f, 0.f, 1.f}, lin{0.f, 0.f, 0.f}, ang{0.f, 0.f, 0.f};
+  q4 rot{1.f, 0.f, 0.f, 0.f};
+  float pot_in = 0.f;
+  int64_t reset_in = 0, progress = 0;
+  if (live) {
+    const float* pp = a.s.torso_position + env * 3;
+    pos = f3{pp[0], pp[1], pp[2]};
+    const float4 r4 = *reinterpret_cast<const float4*>(a.s.torso_rotation + env * 4);
+    rot = q4{r4.x, r4.y, r4.z, r4.w};
+    const float2* vp = reinterpret_cast<const float2*>(a.s.velocities + env * 6);
+    const float2 v0 = vp[0], v1 = vp[1], v2 = vp[2];
+    lin = f3{v0.x, v0.y, v1.x};
+    ang = f3{v1.y, v2.x, v2.y};
+    pot_in = a.b.potentials[env];
+    if (do_done) reset_in = a.b.reset_buf[env];
+    if (do_progress || do_done) progress = a.b.progress_buf[env];
+  }
+
+  // ---- B: pass-through columns into the obs tile
+  scatter_chunk<D, OBS, C_DPOS, false>(c_dpos, tile, 1.0f);  // raw; unscaled per env in C
+  scatter_chunk<D, OBS, C_DVEL, true>(c_dvel, tile, p.dof_vel_scale);
+  scatter_chunk<6 * S, OBS, C_SENS, true>(c_sens, tile, p.contact_force_scale);
+  scatter_chunk<D, OBS, C_ACT, false>(c_act, tile, 1.0f);
+
+  // ---- C: per-env math (locomotion.py:249-263)
+  if (do_progress) progress += 1;  // rl_task.py:289, before is_done reads it
+
+  const f3 target{p.target[0], p.target[1], p.target[2]};
+  f3 to_target{target.x - pos.x, target.y - pos.y, 0.0f};  // :249-250
+  const float prev_pot = pot_in;                           // :252
+  const float pot = (-norm3(to_target)) / p.dt;            // :253
+
+  const q4 inv_start{p.inv_start_rot[0], p.inv_start_rot[1], p.inv_start_rot[2], p.inv_start_rot[3]};
+  const f3 target_dir = normalize3(to_target);
+  const q4 tq = quat_mul(rot, inv_start);
+  const f3 up_vec = quat_rotate(tq, f3{p.basis_vec1[0], p.basis_vec1[1], p.basis_vec1[2]});
+  const f3 heading_vec = quat_rotate(tq, f3{p.basis_vec0[0], p.basis_vec0[1], p.basis_vec0[2]});
+  const float up_proj = up_vec.z;
+  const float heading_proj = dot3(heading_vec, target_dir);
+  const f3 vel_loc = quat_rotate_inverse(tq, lin);
+  const f3 angvel_loc = quat_rotate_inverse(tq, ang);
+  float roll, pitch, yaw;
+  get_euler_xyz(tq, roll, pitch, yaw);
+  (void)pitch;
+  const float walk_target_angle = atan2f(target.z - pos.z, target.x - pos.x);  // z, not y (warp/shared/locomotion.py:347)
+  const float angle_to_target = walk_target_angle - yaw;
+
+  float head[12];
+  head[0] = pos.z;
+  head[1] = vel_loc.x; head[2] = vel_loc.y; head[3] = vel_loc.z;
+  head[4] = angvel_loc.x * p.angular_velocity_scale;
+  head[5] = angvel_loc.y * p.angular_velocity_scale;
+  head[6] = angvel_loc.z * p.angular_velocity_scale;
+  head[7] = normalize_angle(yaw);
+  head[8] = normalize_angle(roll);
+  head[9] = normalize_angle(angle_to_target);
+  head[10] = up_proj;
+  head[11] = heading_proj;
+
+  __syncthreads();  // B's cross-lane LDS writes visible (single-wave workgroup: a wave-local fence)
+
+  float* row = tile + lane * OBS;
+  float dps[D], dvs[D], act[D];
+  if (OBS % 4 == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      *reinterpret_cast<float4*>(row + 4 * k) = make_float4(head[4 * k], head[4 * k + 1], head[4 * k + 2], head[4 * k + 3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) row[k] = head[k];
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    dps[j] = unscale(row[C_DPOS + j], p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :263
+    dvs[j] = row[C_DVEL + j];
+    act[j] = row[C_ACT + j];
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) row[C_DPOS + j] = dps[j];
+
+  if (live) {
+    a.b.potentials[env] = pot;
+    a.b.prev_potentials[env] = prev_pot;
+    if (a.b.up_vec) {
+      float* u = a.b.up_vec + env * 3;
+      u[0] = up_vec.x; u[1] = up_vec.y; u[2] = up_vec.z;
+    }
+    if (a.b.heading_vec) {
+      float* h = a.b.heading_vec + env * 3;
+      h[0] = heading_vec.x; h[1] = heading_vec.y; h[2] = heading_vec.z;
+    }
+    if (do_progress) a.b.progress_buf[env] = progress;
+    if (do_metrics)
+      a.b.rew_buf[env] = reward_of<D, LIMIT>(p, head[0], up_proj, heading_proj, dps, dvs, act, pot, prev_pot);
+  }
+  if (do_done) {
+    // is_done (:290-291): sticky; progress compared in fp32 against float(max_len - 1)
+    int64_t r = head[0] < p.termination_height ? 1 : reset_in;
+    r = (float)progress >= a.max_len_minus_1 ? 1 : r;
+    if (live) a.b.reset_buf[env] = r;
+    const unsigned long long m = __ballot(live && r != 0);
+    if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
+  }
+
+  __syncthreads();  // C's row writes visible to the lane-linear readout
+
+  // ---- D: finished obs tile -> HBM, one contiguous run
+  store_tile<OBS, FULL>(tile, a.b.obs_buf + env0 * OBS, nv * OBS);
+}
+
+template <int D, int S, int LIMIT>
+__global__ __launch_bounds__(WAVE) void locomotion_post_kernel(const LocoPost a) {
+  constexpr int OBS = 12 + 3 * D + 6 * S;
+  __shared__ __align__(16) float tile[TILE * OBS];
+  const int64_t t = blockIdx.x;
+  const int64_t left = a.n - t * TILE;
+  if (left >= TILE)
+    post_tile<D, S, LIMIT, true>(a, tile, t, TILE);
+  else
+    post_tile<D, S, LIMIT, false>(a, tile, t, (int)left);
+}
+
+// ---------------------------------------------------------------- split-stage kernels
+// Used when the host calls calculate_metrics() / is_done() / progress on their own (the
+// RLTask methods stay individually callable); they read obs_buf rows back from memory the
+// way the reference's separate jit functions do.  Not the hot path.
+template <int D, int S, int LIMIT>
+__global__ __launch_bounds__(256) void locomotion_metrics_kernel(const LocoPost a) {
+  constexpr int OBS = 12 + 3 * D + 6 * S;
+  const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= a.n) return;
+  const float* row = a.b.obs_buf + env * OBS;
+  float dps[D], dvs[D], act[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    dps[j] = row[12 + j];
+    dvs[j] = row[12 + D + j];
+    act[j] = a.b.actions[env * D + j];
+  }
+  a.b.rew_buf[env] = reward_of<D, LIMIT>(a.p, row[0], row[10], row[11], dps, dvs, act, a.b.potentials[env],
+                                         a.b.prev_potentials[env]);
+}
+
+__global__ __launch_bounds__(256) void locomotion_done_kernel(const LocoPost a, int obs_width) {
+  const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = env < a.n;
+  int64_t r = 0;
+  if (live) {
+    r = a.b.obs_buf[env * obs_width] < a.p.termination_height ? 1 : a.b.reset_buf[env];
+    r = (float)a.b.progress_buf[env] >= a.max_len_minus_1 ? 1 : r;
+    a.b.reset_buf[env] = r;
+  }
+  const unsigned long long m = __ballot(live && r != 0);
+  if (a.b.reset_workspace && lane_id() == 0) a.b.reset_workspace[env / TILE] = __popcll(m);
+}
+
+__global__ __launch_bounds__(256) void progress_increment_kernel(int64_t* __restrict__ progress, int64_t n) {
+  const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (env < n) progress[env] += 1;
+}
+
+// ---------------------------------------------------------------- pre_physics / reset
+struct LocoPre {
+  oige_locomotion_params p;
+  oige_locomotion_buffers b;
+  oige_locomotion_reset_io r;
+  const float* actions_in;
+  float* actions_out;
+  float* forces_out;
+  int64_t n;
+  uint32_t flags;
+};
+
+// reset_idx for env `i` landing in compacted row `k` (locomotion.py:133-158)
+template <int D>
+__device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const oige_locomotion_buffers& b,
+                                          const oige_locomotion_reset_io& r, int64_t i, int64_t k) {
+  // the 2*D uniform draws: [0,D) -> dof_pos (1st torch.rand, :137), [D,2D) -> dof_vel (2nd, :139)
+  float u[2 * D];
+  if (r.u_pos != nullptr) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      u[j] = r.u_pos[k * D + j];
+      u[D + j] = r.u_vel[k * D + j];
+    }
+  } else {
+#pragma unroll
+    for (int blk = 0; blk < (2 * D + 3) / 4; ++blk) {
+      const u4 c{(uint32_t)i, (uint32_t)blk, (uint32_t)r.step, (uint32_t)(r.step >> 32)};
+      const u4 x = philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+      const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (4 * blk + q < 2 * D) u[4 * blk + q] = u01(w[q]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    // torch_rand_float(lo, hi): (hi - lo) * u + lo, with hi - lo folded in double first (:137,:139)
+    const float dp = 0.4f * u[j] + (-0.2f);
+    const float dv = 0.2f * u[D + j] + (-0.1f);
+    r.dof_pos_out[k * D + j] =
+        tensor_clamp(r.initial_dof_pos[i * D + j] + dp, p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :138
+    r.dof_vel_out[k * D + j] = dv;
+  }
+  const float* ip = r.initial_root_pos + i * 3;
+  const float4 iq = *reinterpret_cast<const float4*>(r.initial_root_rot + i * 4);
+  r.root_pos_out[k * 3 + 0] = ip[0];
+  r.root_pos_out[k * 3 + 1] = ip[1];
+  r.root_pos_out[k * 3 + 2] = ip[2];
+  *reinterpret_cast<float4*>(r.root_rot_out + k * 4) = iq;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) r.root_vel_out[k * 6 + c] = 0.0f;  // :142
+  const f3 tt{p.target[0] - ip[0], p.target[1] - ip[1], 0.0f};   // :151-152
+  const float pot = (-norm3(tt)) / p.dt;                         // :153
+  b.prev_potentials[i] = pot;
+  b.potentials[i] = pot;  // :154
+  b.reset_buf[i] = 0;     // :157
+  b.progress_buf[i] = 0;  // :158
+  r.env_ids[k] = i;
+}
+
+template <int D>
+__global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) {
+  __shared__ int lds4[GROUP_TILES];
+  const int64_t g = blockIdx.x;
+  const int64_t env = g * GROUP + threadIdx.x;
+  const int64_t G = num_groups(a.n);
+  const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
+
+  // forces = actions * joint_gears * power_scale (:125-126), lane-linear over the group's
+  // contiguous 256*D floats; optional clamp (vec_env_rlgames.py:77) and clone (:125)
+  {
+    const int64_t base = g * GROUP * D;
+    const int64_t total = a.n * D;
+    constexpr int NF4 = GROUP * D / 4;
+#pragma unroll
+    for (int it = 0; it < (NF4 + GROUP - 1) / GROUP; ++it) {
+      const int f = it * GROUP + threadIdx.x;
+      if (f >= NF4) break;
+      const int64_t e = base + 4 * (int64_t)f;
+      if (e >= total) break;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      const bool whole = e + 3 < total;
+      if (whole) {
+        const float4 t = *reinterpret_cast<const float4*>(a.actions_in + e);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (e + k < total) v[k] = a.actions_in[e + k];
+      }
+      float fo[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (a.flags & OIGE_PRE_CLAMP_ACTIONS) v[k] = clamp_sym(v[k], a.p.clip_actions);
+        const int col = (4 * f + k) % D;  // the group's run starts at a multiple of D
+        fo[k] = (v[k] * a.p.joint_gears[col]) * a.p.power_scale;
+      }
+      if (whole) {
+        if (a.actions_out) *reinterpret_cast<float4*>(a.actions_out + e) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(a.forces_out + e) = make_float4(fo[0], fo[1], fo[2], fo[3]);
+      } else {
+        for (int k = 0; k < 4; ++k)
+          if (e + k < total) {
+            if (a.actions_out) a.actions_out[e + k] = v[k];
+            a.forces_out[e + k] = fo[k];
+          }
+      }
+    }
+  }
+
+  // compaction rank + reset of the flagged envs (:121-123)
+  const bool flagged = env < a.n && a.b.reset_buf[env] != 0;
+  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
+  if (flagged) reset_env<D>(a.p, a.b, a.r, env, k);
+  if (g == 0 && threadIdx.x == 0) *a.r.count = (int64_t)group_offsets[G];
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void locomotion_reset_idx_kernel(const LocoPre a, int64_t max_ids) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= max_ids || k >= *a.r.count) return;
+  const int64_t i = a.r.env_ids[k];
+  if (i < 0 || i >= a.n) return;
+  reset_env<D>(a.p, a.b, a.r, i, k);
+}
+
+// ---------------------------------------------------------------- host dispatch
+static int check_params(const oige_locomotion_params* p) {
+  OIGE_REQUIRE(p != nullptr, "locomotion: null params");
+  const bool ant = p->num_dof == 8 && p->num_sensors == 4;
+  const bool humanoid = p->num_dof == 21 && p->num_sensors == 2;
+  OIGE_REQUIRE(ant || humanoid, "locomotion: unsupported (num_dof=%d, num_sensors=%d); built for Ant (8,4) and Humanoid (21,2)",
+               p->num_dof, p->num_sensors);
+  OIGE_REQUIRE(p->limit_cost_kind == 0 || p->limit_cost_kind == 1, "locomotion: limit_cost_kind must be 0 or 1");
+  return OIGE_OK;
+}
+
+template <int D, int S>
+static int launch_post(const LocoPost& a, hipStream_t s) {
+  const int64_t T = num_tiles(a.n);
+  if (T == 0) return OIGE_OK;
+  if (a.stages & OIGE_STAGE_OBS) {
+    if (a.p.limit_cost_kind == 0)
+      hipLaunchKernelGGL((locomotion_post_kernel<D, S, 0>), dim3((unsigned)T), dim3(WAVE), 0, s, a);
+    else
+      hipLaunchKernelGGL((locomotion_post_kernel<D, S, 1>), dim3((unsigned)T), dim3(WAVE), 0, s, a);
+    return check_launch("locomotion_post_kernel");
+  }
+  const unsigned blocks = (unsigned)((a.n + 255) / 256);
+  if (a.stages & OIGE_STAGE_PROGRESS) {
+    hipLaunchKernelGGL(progress_increment_kernel, dim3(blocks), dim3(256), 0, s, a.b.progress_buf, a.n);
+    if (int rc = check_launch("progress_increment_kernel")) return rc;
+  }
+  if (a.stages & OIGE_STAGE_METRICS) {
+    if (a.p.limit_cost_kind == 0)
+      hipLaunchKernelGGL((locomotion_metrics_kernel<D, S, 0>), dim3(blocks), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((locomotion_metrics_kernel<D, S, 1>), dim3(blocks), dim3(256), 0, s, a);
+    if (int rc = check_launch("locomotion_metrics_kernel")) return rc;
+  }
+  if (a.stages & OIGE_STAGE_DONE) {
+    hipLaunchKernelGGL(locomotion_done_kernel, dim3(blocks), dim3(256), 0, s, a, 12 + 3 * D + 6 * S);
+    if (int rc = check_launch("locomotion_done_kernel")) return rc;
+  }
+  return OIGE_OK;
+}
+
+template <int D>
+static int launch_pre(const LocoPre& a, hipStream_t s) {
+  const int64_t G = num_groups(a.n);
+  if (G == 0) return OIGE_OK;
+  if (!(a.flags & OIGE_PRE_COUNTS_VALID))
+    if (int rc = launch_count_flags(a.b.reset_buf, a.n, a.b.reset_workspace, s)) return rc;
+  if (int rc = launch_scan_groups(a.n, a.b.reset_workspace, s)) return rc;
+  hipLaunchKernelGGL((locomotion_pre_kernel<D>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  return check_launch("locomotion_pre_kernel");
+}
+
+static int check_reset_io(const oige_locomotion_reset_io* r) {
+  OIGE_REQUIRE(r != nullptr, "locomotion: null reset_io");
+  OIGE_REQUIRE(r->initial_root_pos && r->initial_root_rot && r->initial_dof_pos, "locomotion: null initial_* pointer");
+  OIGE_REQUIRE((r->u_pos == nullptr) == (r->u_vel == nullptr), "locomotion: pass both u_pos and u_vel or neither");
+  OIGE_REQUIRE(r->env_ids && r->count && r->dof_pos_out && r->dof_vel_out && r->root_pos_out && r->root_rot_out &&
+                   r->root_vel_out,
+               "locomotion: null reset output pointer");
+  OIGE_REQUIRE(aligned16(r->initial_root_rot) && aligned16(r->root_rot_out), "locomotion: (N,4) buffers must be 16-byte aligned");
+  return OIGE_OK;
+}
+
+}  // namespace oige
+
+using namespace oige;
+
+extern "C" {
+
+int oige_locomotion_post_physics(const oige_locomotion_params* params, const oige_locomotion_state* state,
+                                 const oige_locomotion_buffers* buffers, int64_t num_envs, uint32_t stages,
+                                 oige_stream_t stream) {
+  if (int rc = check_params(params)) return rc;
+  OIGE_REQUIRE(buffers != nullptr, "locomotion_post_physics: null buffers");
+  OIGE_REQUIRE(num_envs >= 0 && num_envs < ((int64_t)1 << 31) / 128, "locomotion_post_physics: num_envs %lld out of range",
+               (long long)num_envs);
+  OIGE_REQUIRE((stages & ~OIGE_STAGE_ALL) == 0 && stages != 0, "locomotion_post_physics: bad stages mask 0x%x", stages);
+  const oige_locomotion_buffers& b = *buffers;
+  OIGE_REQUIRE(b.obs_buf && b.progress_buf, "locomotion_post_physics: null obs_buf/progress_buf");
+  if (stages & (OIGE_STAGE_OBS | OIGE_STAGE_METRICS))
+    OIGE_REQUIRE(b.potentials && b.prev_potentials && b.actions, "locomotion_post_physics: null potentials/actions");
+  if (stages & OIGE_STAGE_METRICS) OIGE_REQUIRE(b.rew_buf, "locomotion_post_physics: null rew_buf");
+  if (stages & OIGE_STAGE_DONE) OIGE_REQUIRE(b.reset_buf, "locomotion_post_physics: null reset_buf");
+  LocoPost a;
+  a.p = *params;
+  a.b = b;
+  a.n = num_envs;
+  a.stages = stages;
+  a.max_len_minus_1 = (float)((double)params->max_episode_length - 1.0);
+  if (stages & OIGE_STAGE_OBS) {
+    OIGE_REQUIRE(state != nullptr, "locomotion_post_physics: null state");
+    a.s = *state;
+    OIGE_REQUIRE(a.s.torso_position && a.s.torso_rotation && a.s.velocities && a.s.dof_pos && a.s.dof_vel &&
+                     a.s.sensor_force_torques,
+                 "locomotion_post_physics: null state pointer");
+    OIGE_REQUIRE(aligned16(a.s.torso_rotation) && aligned16(a.s.dof_pos) && aligned16(a.s.dof_vel) &&
+                     aligned16(a.s.sensor_force_torques) && aligned16(b.actions) && aligned16(b.obs_buf) &&
+                     (reinterpret_cast<uintptr_t>(a.s.velocities) & 7u) == 0,
+                 "locomotion_post_physics: state/obs/actions buffers must be 16-byte aligned (velocities 8)");
+  } else {
+    a.s = oige_locomotion_state{};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  return params->num_dof == 8 ? launch_post<8, 4>(a, s) : launch_post<21, 2>(a, s);
+}
+
+int oige_locomotion_pre_physics(const oige_locomotion_params* params, const float* actions_in,
+                                const oige_locomotion_buffers* buffers, const oige_locomotion_reset_io* reset_io,
+                                float* actions_out, float* forces_out, int64_t num_envs, uint32_t flags,
+                                oige_stream_t stream) {
+  if (int rc = check_params(params)) return rc;
+  if (int rc = check_reset_io(reset_io)) return rc;
+  OIGE_REQUIRE(buffers && actions_in && forces_out, "locomotion_pre_physics: null pointer");
+  OIGE_REQUIRE(num_envs >= 0 && num_envs < ((int64_t)1 << 31) / 128, "locomotion_pre_physics: num_envs %lld out of range",
+               (long long)num_envs);
+  const oige_locomotion_buffers& b = *buffers;
+  OIGE_REQUIRE(b.reset_buf && b.progress_buf && b.potentials && b.prev_potentials && b.reset_workspace,
+               "locomotion_pre_physics: null reset/progress/potentials/workspace");
+  OIGE_REQUIRE(aligned16(actions_in) && aligned16(forces_out) && aligned16(actions_out) && aligned16(b.reset_workspace),
+               "locomotion_pre_physics: actions/forces/workspace must be 16-byte aligned");
+  LocoPre a;
+  a.p = *params;
+  a.b = b;
+  a.r = *reset_io;
+  a.actions_in = actions_in;
+  a.actions_out = actions_out;
+  a.forces_out = forces_out;
+  a.n = num_envs;
+  a.flags = flags;
+  hipStream_t s = (hipStream_t)stream;
+  return params->num_dof == 8 ? launch_pre<8>(a, s) : launch_pre<21>(a, s);
+}
+
+int oige_locomotion_reset_idx(const oige_locomotion_params* params, const oige_locomotion_buffers* buffers,
+                              const oige_locomotion_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                              oige_stream_t stream) {
+  if (int rc = check_params(params)) return rc;
+  if (int rc = check_reset_io(reset_io)) return rc;
+  OIGE_REQUIRE(buffers != nullptr, "locomotion_reset_idx: null buffers");
+  OIGE_REQUIRE(num_envs >= 0 && max_ids >= 0 && max_ids <= num_envs, "locomotion_reset_idx: bad num_envs/max_ids");
+  const oige_locomotion_buffers& b = *buffers;
+  OIGE_REQUIRE(b.reset_buf && b.progress_buf && b.potentials && b.prev_potentials,
+               "locomotion_reset_idx: null reset/progress/potentials");
+  if (max_ids == 0) return OIGE_OK;
+  LocoPre a;
+  a.p = *params;
+  a.b = b;
+  a.r = *reset_io;
+  a.actions_in = nullptr;
+  a.actions_out = nullptr;
+  a.forces_out = nullptr;
+  a.n = num_envs;
+  a.flags = 0;
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((max_ids + 255) / 256);
+  if (params->num_dof == 8)
+    hipLaunchKernelGGL((locomotion_reset_idx_kernel<8>), dim3(blocks), dim3(256), 0, s, a, max_ids);
+  else
+    hipLaunchKernelGGL((locomotion_reset_idx_kernel<21>), dim3(blocks), dim3(256), 0, s, a, max_ids);
+  return check_launch("locomotion_reset_idx_kernel");
+}
+
+}  // extern "C"

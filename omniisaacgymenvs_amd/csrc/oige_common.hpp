@@ -1,0 +1,85 @@
+// Host/device plumbing shared by every translation unit of liboige_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/oige_hip.h"
+
+namespace oige {
+
+constexpr int WAVE = 64;              // gfx950 wavefront
+constexpr int TILE = OIGE_TILE_ENVS;  // envs per wave-tile
+constexpr int GROUP_TILES = 4;        // tiles per 256-env group (one pre_physics workgroup)
+constexpr int GROUP = TILE * GROUP_TILES;
+static_assert(TILE == WAVE, "one wavefront owns one tile of envs");
+
+// thread-local last-error message (defined in oige_core.hip)
+char* error_buffer();
+constexpr size_t ERROR_BUFFER_BYTES = 512;
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(error_buffer(), ERROR_BUFFER_BYTES, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(OIGE_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return OIGE_OK;
+}
+
+#define OIGE_REQUIRE(cond, ...)                                 \
+  do {                                                          \
+    if (!(cond)) return ::oige::fail(OIGE_EINVAL, __VA_ARGS__); \
+  } while (0)
+
+__host__ __device__ inline int64_t num_tiles(int64_t n) { return (n + TILE - 1) / TILE; }
+__host__ __device__ inline int64_t num_groups(int64_t n) { return (n + GROUP - 1) / GROUP; }
+
+// Reset workspace layout (int32): [ tile counts, padded to a multiple of 4 | group offsets (G+1) ].
+// tile_counts[t]    = number of non-zero reset flags in envs [64t, 64t+64)
+// group_offsets[g]  = number of non-zero flags in envs [0, 256g);  group_offsets[G] = total
+__host__ __device__ inline int64_t padded_tiles(int64_t n) { return num_groups(n) * GROUP_TILES; }
+inline int64_t workspace_ints(int64_t n) { return padded_tiles(n) + num_groups(n) + 1; }
+
+// launches the count (optional) and scan kernels on `stream` (oige_core.hip)
+int launch_count_flags(const int64_t* flags, int64_t n, int32_t* ws, hipStream_t stream);
+int launch_scan_groups(int64_t n, int32_t* ws, hipStream_t stream);
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int rank_below(unsigned long long mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+
+// Rank (position in the ascending compacted id list) of env `env` if `flagged`, for a
+// 256-thread workgroup that owns group `g` (envs [256g, 256g+256)).  Needs 4 ints of LDS.
+// Every thread of the workgroup must call it.  Returns -1 for unflagged lanes.
+__device__ __forceinline__ int64_t group_rank(bool flagged, const int32_t* group_offsets, int64_t g, int* lds4) {
+  const unsigned long long mask = __ballot(flagged);
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == 0) lds4[w] = __popcll(mask);
+  __syncthreads();
+  int before = 0;
+#pragma unroll
+  for (int i = 0; i < GROUP_TILES; ++i) before += (i < w) ? lds4[i] : 0;
+  const int64_t r = (int64_t)group_offsets[g] + before + rank_below(mask);
+  return flagged ? r : -1;
+}
+
+}  // namespace oige

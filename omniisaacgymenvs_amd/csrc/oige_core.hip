@@ -1,0 +1,133 @@
+// liboige_hip.so core: error reporting, version, and the ordered stream compaction that
+// replaces `reset_buf.nonzero(as_tuple=False).squeeze(-1)` + `len()` (a forced device->host
+// sync in the reference: tasks/shared/locomotion.py:121-122, cartpole.py:112-113,
+// in_hand_manipulation.py:318-319, anymal_terrain.py:433, randomize.py:284,315).
+//
+// Three small kernels, all HBM/L2-bound integer work, no host sync, count stays on device:
+//   count : one ballot+popcount per wave            -> tile_counts[t]      (8 B/env read)
+//   scan  : one workgroup, exclusive scan per 256-env group -> group_offsets[g], total
+//   emit  : per wave, rank = group offset + earlier waves + mbcnt(ballot); ids[rank] = env
+// The task kernels (locomotion.hip, cartpole.hip, ...) fuse `count` into their DONE stage and
+// `emit` into their reset stage, so a steady-state step only adds the tiny `scan` launch.
+#include "oige_common.hpp"
+
+namespace oige {
+
+char* error_buffer() {
+  static thread_local char buf[ERROR_BUFFER_BYTES] = {0};
+  return buf;
+}
+
+__global__ __launch_bounds__(GROUP) void count_flags_kernel(const int64_t* __restrict__ flags, int64_t n,
+                                                          int32_t* __restrict__ tile_counts) {
+  const int64_t env = (int64_t)blockIdx.x * GROUP + threadIdx.x;
+  const bool f = env < n && flags[env] != 0;
+  const unsigned long long mask = __ballot(f);
+  if (lane_id() == 0) tile_counts[(int64_t)blockIdx.x * GROUP_TILES + (threadIdx.x >> 6)] = __popcll(mask);
+}
+
+// One workgroup of 1024 threads; thread i owns a contiguous run of groups.
+constexpr int SCAN_THREADS = 1024;
+__global__ __launch_bounds__(SCAN_THREADS) void scan_groups_kernel(const int32_t* __restrict__ tile_counts,
+                                                                   int64_t n_groups,
+                                                                   int32_t* __restrict__ group_offsets) {
+  __shared__ int wave_tot[SCAN_THREADS / WAVE];
+  const int tid = threadIdx.x;
+  const int64_t per = (n_groups + SCAN_THREADS - 1) / SCAN_THREADS;
+  const int64_t g0 = (int64_t)tid * per;
+  const int64_t g1 = g0 + per < n_groups ? g0 + per : n_groups;
+  const int4* c4 = reinterpret_cast<const int4*>(tile_counts);  // GROUP_TILES == 4 counts per group
+  int mine = 0;
+  for (int64_t g = g0; g < g1; ++g) {
+    const int4 c = c4[g];
+    mine += (c.x + c.y) + (c.z + c.w);
+  }
+  // inclusive scan of `mine` across the wave, then across waves
+  int incl = mine;
+#pragma unroll
+  for (int off = 1; off < WAVE; off <<= 1) {
+    const int up = __shfl_up(incl, off, WAVE);
+    if (lane_id() >= off) incl += up;
+  }
+  const int w = tid >> 6;
+  if (lane_id() == WAVE - 1) wave_tot[w] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int i = 0; i < w; ++i) base += wave_tot[i];
+  int run = base + incl - mine;  // exclusive prefix at g0
+  for (int64_t g = g0; g < g1; ++g) {
+    group_offsets[g] = run;
+    const int4 c = c4[g];
+    run += (c.x + c.y) + (c.z + c.w);
+  }
+  if (tid == SCAN_THREADS - 1) {
+    int total = 0;
+    for (int i = 0; i < SCAN_THREADS / WAVE; ++i) total += wave_tot[i];
+    group_offsets[n_groups] = total;
+  }
+}
+
+__global__ __launch_bounds__(GROUP) void emit_ids_kernel(const int64_t* __restrict__ flags, int64_t n,
+                                                       const int32_t* __restrict__ group_offsets, int64_t n_groups,
+                                                       int64_t* __restrict__ ids, int64_t* __restrict__ count) {
+  __shared__ int lds4[GROUP_TILES];
+  const int64_t g = blockIdx.x;
+  const int64_t env = g * GROUP + threadIdx.x;
+  const bool f = env < n && flags[env] != 0;
+  const int64_t r = group_rank(f, group_offsets, g, lds4);
+  if (f) ids[r] = env;
+  if (g == 0 && threadIdx.x == 0) *count = (int64_t)group_offsets[n_groups];
+}
+
+int launch_count_flags(const int64_t* flags, int64_t n, int32_t* ws, hipStream_t stream) {
+  const int64_t G = num_groups(n);
+  if (G == 0) return OIGE_OK;
+  hipLaunchKernelGGL(count_flags_kernel, dim3((unsigned)G), dim3(GROUP), 0, stream, flags, n, ws);
+  return check_launch("count_flags_kernel");
+}
+
+int launch_scan_groups(int64_t n, int32_t* ws, hipStream_t stream) {
+  const int64_t G = num_groups(n);
+  hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, ws, G, ws + padded_tiles(n));
+  return check_launch("scan_groups_kernel");
+}
+
+}  // namespace oige
+
+using namespace oige;
+
+extern "C" {
+
+const char* oige_last_error(void) { return error_buffer(); }
+int oige_version(void) { return OIGE_ABI_VERSION; }
+int64_t oige_num_tiles(int64_t n) { return n < 0 ? 0 : num_tiles(n); }
+int64_t oige_workspace_ints(int64_t n) { return n < 0 ? 0 : workspace_ints(n); }
+
+int oige_count_flags_i64(const int64_t* flags, int64_t n, int32_t* workspace, oige_stream_t stream) {
+  OIGE_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "count_flags: num_envs %lld out of range", (long long)n);
+  OIGE_REQUIRE(flags && workspace, "count_flags: null pointer");
+  OIGE_REQUIRE(aligned16(workspace), "count_flags: workspace must be 16-byte aligned");
+  return launch_count_flags(flags, n, workspace, (hipStream_t)stream);
+}
+
+int oige_compact_i64(const int64_t* flags, int64_t n, int32_t* workspace, int64_t* ids_out, int64_t* count_out,
+                     oige_stream_t stream) {
+  OIGE_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "compact: num_envs %lld out of range", (long long)n);
+  OIGE_REQUIRE(flags && workspace && ids_out && count_out, "compact: null pointer");
+  OIGE_REQUIRE(aligned16(workspace), "compact: workspace must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_count_flags(flags, n, workspace, s);
+  if (rc) return rc;
+  rc = launch_scan_groups(n, workspace, s);
+  if (rc) return rc;
+  const int64_t G = num_groups(n);
+  if (G > 0) {
+    hipLaunchKernelGGL(emit_ids_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, flags, n, workspace + padded_tiles(n), G,
+                       ids_out, count_out);
+    return check_launch("emit_ids_kernel");
+  }
+  return hipMemsetAsync(count_out, 0, sizeof(int64_t), s) == hipSuccess ? OIGE_OK
+                                                                        : fail(OIGE_ELAUNCH, "compact: memset failed");
+}
+
+}  // extern "C"

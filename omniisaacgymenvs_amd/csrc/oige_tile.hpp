@@ -1,0 +1,100 @@
+// Wave-tile staging: one wavefront owns a tile of 64 consecutive envs.
+//
+// The views hand over row-major (N,K) arrays.  A tile's slice of such an array is ONE
+// contiguous run of 64*K floats, so the wave moves it with lane-linear 16-byte accesses
+// (64 lanes x 16 B = 1 KiB per instruction, fully coalesced) and transposes through LDS,
+// instead of each lane walking its own K-float row at a K*4-byte stride.
+#pragma once
+#include "oige_common.hpp"
+
+namespace oige {
+
+template <int K>
+struct Chunk {
+  static constexpr int NF4 = (TILE * K) / 4;          // float4 pieces in a full tile (TILE*K % 4 == 0)
+  static constexpr int ITERS = (NF4 + WAVE - 1) / WAVE;  // per-lane float4 count
+  static constexpr bool EXACT = (NF4 % WAVE) == 0;       // no lane masking needed on a full tile
+  float4 v[ITERS];
+};
+
+// Load the tile's contiguous run.  `src` points at the tile's first float and is 16-byte
+// aligned (tile start = 64*K floats = multiple of 256 B past a 16-byte aligned base).
+// `valid` = number of floats that exist (64*K on a full tile).
+template <int K, bool FULL>
+__device__ __forceinline__ void load_chunk(Chunk<K>& c, const float* __restrict__ src, int valid) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int it = 0; it < Chunk<K>::ITERS; ++it) {
+    const int f = it * WAVE + lane;
+    const int e = 4 * f;
+    if (FULL) {
+      if (Chunk<K>::EXACT || f < Chunk<K>::NF4)
+        c.v[it] = *reinterpret_cast<const float4*>(src + e);
+      else
+        c.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e + 3 < valid) {
+        t = *reinterpret_cast<const float4*>(src + e);
+      } else {
+        if (e + 0 < valid) t.x = src[e + 0];
+        if (e + 1 < valid) t.y = src[e + 1];
+        if (e + 2 < valid) t.z = src[e + 2];
+      }
+      c.v[it] = t;
+    }
+  }
+}
+
+// Scatter a loaded run into the (64 x ROW) LDS tile at column COL0, multiplying by `s`
+// (MUL=false: plain copy).  Element e of the run belongs to env e / K, column e % K.
+template <int K, int ROW, int COL0, bool MUL>
+__device__ __forceinline__ void scatter_chunk(const Chunk<K>& c, float* __restrict__ tile, float s) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int it = 0; it < Chunk<K>::ITERS; ++it) {
+    const int f = it * WAVE + lane;
+    if (!Chunk<K>::EXACT && f >= Chunk<K>::NF4) continue;
+    const int e = 4 * f;
+    float4 t = c.v[it];
+    if (MUL) { t.x *= s; t.y *= s; t.z *= s; t.w *= s; }
+    if ((K % 4 == 0) && (ROW % 4 == 0) && (COL0 % 4 == 0)) {
+      const int env = e / K, col = e % K;  // a float4 never straddles rows when K % 4 == 0
+      *reinterpret_cast<float4*>(tile + env * ROW + COL0 + col) = t;
+    } else {
+      const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ee = e + k;
+        tile[(ee / K) * ROW + COL0 + (ee % K)] = tv[k];
+      }
+    }
+  }
+}
+
+// Store the assembled (64 x ROW) LDS tile as one contiguous run of `valid` floats.
+template <int ROW, bool FULL>
+__device__ __forceinline__ void store_tile(const float* __restrict__ tile, float* __restrict__ dst, int valid) {
+  constexpr int NF4 = (TILE * ROW) / 4;
+  constexpr int ITERS = (NF4 + WAVE - 1) / WAVE;
+  const int lane = lane_id();
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int f = it * WAVE + lane;
+    const int e = 4 * f;
+    if (FULL) {
+      if ((NF4 % WAVE) == 0 || f < NF4)
+        *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(tile + e);
+    } else if (f < NF4) {
+      if (e + 3 < valid) {
+        *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(tile + e);
+      } else {
+        if (e + 0 < valid) dst[e + 0] = tile[e + 0];
+        if (e + 1 < valid) dst[e + 1] = tile[e + 1];
+        if (e + 2 < valid) dst[e + 2] = tile[e + 2];
+      }
+    }
+  }
+}
+
+}  // namespace oige

@@ -1,0 +1,156 @@
+"""Stand-in for the delegated layer L0 (PhysX tensor API): synthetic state behind the getters
+the task math reads and the setters it writes.  There is no Isaac Sim on ROCm; physics stays
+out of scope (BASELINE.json north_star), so ``SyntheticWorld.step`` integrates nothing.
+
+The view mirrors the slice of ``omni.isaac.core`` ArticulationView the reference's hot path
+uses (tasks/shared/locomotion.py:76-84,128-149; tasks/cartpole.py:92-93,122,139-140):
+getters with ``clone=False`` hand out the internal buffers, setters scatter rows at ``indices``.
+
+Extension for the sync-free path: every setter also accepts ``count=<device int64 scalar>``
+with full-capacity ``values``/``indices`` buffers (rows past ``count`` are undefined).  PhysX
+would consume (values, indices, count) on the device; this stand-in either applies them with a
+host read of ``count`` (``apply_resets=True``: functional tests) or drops them
+(``apply_resets=False``: benchmarking the task math alone).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+Tensor = torch.Tensor
+
+
+class SyntheticWorld:
+    """``env.world`` as the tasks and VecEnvRLGames use it (vec_env_rlgames.py:81-90, locomotion.py:118)."""
+
+    def __init__(self) -> None:
+        self._playing = True
+        self.steps = 0
+
+    def is_playing(self) -> bool:
+        return self._playing
+
+    def play(self) -> None:
+        self._playing = True
+
+    def stop(self) -> None:
+        self._playing = False
+
+    def step(self, render: bool = False) -> None:
+        self.steps += 1
+
+    def reset(self) -> None:
+        self.steps = 0
+
+
+class SyntheticArticulationView:
+    def __init__(
+        self,
+        name: str,
+        count: int,
+        num_dof: int,
+        device,
+        num_bodies: int = 1,
+        dof_limits: Optional[Tensor] = None,
+        dof_names: Optional[Dict[str, int]] = None,
+        body_names: Optional[Dict[str, int]] = None,
+        apply_resets: bool = True,
+    ) -> None:
+        self.name = name
+        self.count = count
+        self.num_dof = num_dof
+        self.num_bodies = num_bodies
+        self._device = torch.device(device)
+        self.apply_resets = apply_resets
+        self.sensor_bodies_only = True  # measured_joint_forces holds only the force-sensor bodies, in task order
+        f = dict(dtype=torch.float32, device=self._device)
+        self.positions = torch.zeros((count, 3), **f)
+        self.orientations = torch.zeros((count, 4), **f)
+        self.orientations[:, 0] = 1.0
+        self.velocities = torch.zeros((count, 6), **f)
+        self.joint_positions = torch.zeros((count, num_dof), **f)
+        self.joint_velocities = torch.zeros((count, num_dof), **f)
+        self.joint_efforts = torch.zeros((count, num_dof), **f)
+        self.joint_position_targets = torch.zeros((count, num_dof), **f)
+        self.measured_joint_forces = torch.zeros((count, num_bodies, 6), **f)
+        if dof_limits is None:
+            dof_limits = torch.stack([-torch.ones(num_dof), torch.ones(num_dof)], dim=-1)
+        self._dof_limits = dof_limits.to(**f).unsqueeze(0)  # (1, D, 2); the tasks read row 0 (ant.py:90-92)
+        self._dof_names = dof_names or {}
+        self._body_indices = body_names or {}
+
+    # ------------------------------------------------------------------ getters
+    def get_world_poses(self, clone: bool = True):
+        if clone:
+            return self.positions.clone(), self.orientations.clone()
+        return self.positions, self.orientations
+
+    def get_velocities(self, clone: bool = True) -> Tensor:
+        return self.velocities.clone() if clone else self.velocities
+
+    def get_joint_positions(self, clone: bool = True) -> Tensor:
+        return self.joint_positions.clone() if clone else self.joint_positions
+
+    def get_joint_velocities(self, clone: bool = True) -> Tensor:
+        return self.joint_velocities.clone() if clone else self.joint_velocities
+
+    def get_measured_joint_forces(self, joint_indices: Optional[Tensor] = None, clone: bool = False) -> Tensor:
+        """(N, len(joint_indices), 6).  The synthetic view stores exactly the sensor bodies the task
+        registered (``sensor_bodies_only``), so the common call returns the buffer itself."""
+        if joint_indices is None or self.sensor_bodies_only:
+            return self.measured_joint_forces
+        return self.measured_joint_forces[:, joint_indices, :]
+
+    def get_dof_limits(self) -> Tensor:
+        return self._dof_limits
+
+    def get_dof_index(self, name: str) -> int:
+        return self._dof_names[name]
+
+    # ------------------------------------------------------------------ setters
+    def _rows(self, indices, count):
+        if count is None:
+            return None if indices is None else indices.long()
+        if not self.apply_resets:
+            return False
+        n = int(count.item())  # the host read PhysX would not need; test mode only
+        return indices[:n].long()
+
+    def _scatter(self, buf: Tensor, values: Tensor, indices, count) -> None:
+        rows = self._rows(indices, count)
+        if rows is False:
+            return
+        if rows is None:
+            buf.copy_(values)
+        else:
+            buf[rows] = values[: rows.shape[0]]
+
+    def set_joint_positions(self, positions: Tensor, indices=None, count=None) -> None:
+        self._scatter(self.joint_positions, positions, indices, count)
+
+    def set_joint_velocities(self, velocities: Tensor, indices=None, count=None) -> None:
+        self._scatter(self.joint_velocities, velocities, indices, count)
+
+    def set_joint_efforts(self, efforts: Tensor, indices=None, count=None) -> None:
+        # the common case (all envs, arange indices) keeps a reference instead of copying N*D floats
+        if indices is None or (count is None and indices.shape[0] == self.count):
+            self.joint_efforts = efforts
+        else:
+            self._scatter(self.joint_efforts, efforts, indices, count)
+
+    def set_joint_position_targets(self, positions: Tensor, indices=None, count=None) -> None:
+        if indices is None or (count is None and indices.shape[0] == self.count):
+            self.joint_position_targets = positions
+        else:
+            self._scatter(self.joint_position_targets, positions, indices, count)
+
+    def set_world_poses(self, positions: Optional[Tensor] = None, orientations: Optional[Tensor] = None, indices=None,
+                        count=None) -> None:
+        if positions is not None:
+            self._scatter(self.positions, positions, indices, count)
+        if orientations is not None:
+            self._scatter(self.orientations, orientations, indices, count)
+
+    def set_velocities(self, velocities: Tensor, indices=None, count=None) -> None:
+        self._scatter(self.velocities, velocities, indices, count)

@@ -1,0 +1,199 @@
+"""RLTask: the task base class contract of the reference, kept so task code and the
+VecEnvRLGames wrapper work unchanged (/root/reference/omniisaacgymenvs/tasks/base/rl_task.py).
+
+Kept: constructor signature and attribute names (:55-156), the buffer dtype contract of
+``cleanup`` (:158-167: obs/states/rew fp32, reset_buf int64 = 1, progress_buf int64 = 0),
+``reset`` (:274-276), the ``post_physics_step`` stage order (:278-298) and the ``world`` /
+``cfg`` properties (:300-317).  Out of scope and absent: GridCloner/USD scene cloning,
+cameras, replicator (they belong to the delegated simulator).  ``set_up_scene`` only lays the
+env origins out on the same square grid the cloner would use.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ...utils.domain_randomization.randomize import Randomizer
+from ...utils.spaces import Box
+
+
+class RLTask:
+    def __init__(self, name, env, offset=None) -> None:
+        self._name = name
+        self._offset = offset
+
+        if not hasattr(self, "_cfg"):
+            self._cfg = {}
+        if not hasattr(self, "_task_cfg"):
+            self._task_cfg = {}
+
+        self._rand_seed = self._cfg["seed"]
+        self.test = self._cfg["test"]
+        self._device = self._cfg["sim_device"]
+
+        self._dr_randomizer = Randomizer(self._cfg, self._task_cfg)
+
+        self.enable_cameras = self._task_cfg.get("sim", {}).get("enable_cameras", False)
+        self.randomize_actions = False
+        self.randomize_observations = False
+
+        env_cfg = self._task_cfg.get("env", {})
+        self.clip_obs = env_cfg.get("clipObservations", np.inf)
+        self.clip_actions = env_cfg.get("clipActions", np.inf)
+        self.rl_device = self._cfg.get("rl_device", "cuda:0")
+
+        self.control_frequency_inv = env_cfg.get("controlFrequencyInv", 1)
+        self.rendering_interval = self._task_cfg.get("renderingInterval", 1)
+
+        self._env = env
+        self.is_extension = False
+
+        for attr, default in (
+            ("_num_agents", 1),
+            ("_num_states", 0),
+            ("_num_envs", 0),
+            ("_num_actions", 0),
+            ("_num_observations", 0),
+        ):
+            if not hasattr(self, attr):
+                setattr(self, attr, default)
+
+        if not hasattr(self, "action_space"):
+            self.action_space = Box(-np.ones(self._num_actions, dtype=np.float32), np.ones(self._num_actions, dtype=np.float32))
+        if not hasattr(self, "observation_space"):
+            hi = np.full(self._num_observations, np.inf, dtype=np.float32)
+            self.observation_space = Box(-hi, hi)
+        if not hasattr(self, "state_space"):
+            hi = np.full(self._num_states, np.inf, dtype=np.float32)
+            self.state_space = Box(-hi, hi)
+
+        self._env_pos = torch.tensor([], dtype=torch.float32, device=self._device)
+        self.cleanup()
+
+    # ------------------------------------------------------------------ buffers
+    def cleanup(self) -> None:
+        """Allocate the RL buffers with the reference's dtypes and initial values (:158-167)."""
+        dev = self._device
+        self.obs_buf = torch.zeros((self._num_envs, self._num_observations), device=dev, dtype=torch.float)
+        self.states_buf = torch.zeros((self._num_envs, self._num_states), device=dev, dtype=torch.float)
+        self.rew_buf = torch.zeros(self._num_envs, device=dev, dtype=torch.float)
+        self.reset_buf = torch.ones(self._num_envs, device=dev, dtype=torch.long)
+        self.progress_buf = torch.zeros(self._num_envs, device=dev, dtype=torch.long)
+        self.extras = {}
+
+    # ------------------------------------------------------------------ scene
+    def set_up_scene(self, scene=None, **_ignored) -> None:
+        """Env origins on the square grid GridCloner(spacing) produces (:189-207); no USD."""
+        spacing = getattr(self, "_env_spacing", 1.0)
+        n = self._num_envs
+        per_row = max(int(math.ceil(math.sqrt(max(n, 1)))), 1)
+        idx = torch.arange(n, dtype=torch.float32)
+        rows = torch.floor(idx / per_row)
+        cols = idx - rows * per_row
+        off = (per_row - 1) * spacing / 2.0
+        pos = torch.stack([rows * spacing - off, cols * spacing - off, torch.zeros(n)], dim=-1)
+        self._env_pos = pos.to(device=self._device, dtype=torch.float)
+
+    def initialize_views(self, scene=None) -> None:
+        self.set_up_scene(scene)
+
+    @property
+    def default_base_env_path(self) -> str:
+        return "/World/envs"
+
+    @property
+    def default_zero_env_path(self) -> str:
+        return f"{self.default_base_env_path}/env_0"
+
+    # ------------------------------------------------------------------ RL interface
+    def reset(self) -> None:
+        """Flag every env for reset (:274-276; rebinds, as the reference does)."""
+        self.reset_buf = torch.ones_like(self.reset_buf)
+
+    def post_physics_step(self):
+        """progress += 1, then obs -> states -> metrics -> done -> extras (:289-298).
+
+        Task classes with a fused HIP kernel override this with one launch that keeps the
+        same order; this generic version drives the individually callable methods.
+        """
+        self.progress_buf[:] += 1
+        if self._env.world.is_playing():
+            self.get_observations()
+            self.get_states()
+            self.calculate_metrics()
+            self.is_done()
+            self.get_extras()
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def get_states(self):
+        return self.states_buf
+
+    def get_extras(self):
+        return self.extras
+
+    def pre_physics_step(self, actions) -> None:
+        raise NotImplementedError
+
+    def get_observations(self):
+        raise NotImplementedError
+
+    def calculate_metrics(self) -> None:
+        raise NotImplementedError
+
+    def is_done(self) -> None:
+        raise NotImplementedError
+
+    def post_reset(self) -> None:
+        pass
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def name(self) -> str:
+        return self._name
+
+    @property
+    def world(self):
+        return self._env.world
+
+    @property
+    def cfg(self):
+        return self._cfg
+
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def num_envs(self) -> int:
+        return self._num_envs
+
+    @property
+    def num_actions(self) -> int:
+        return self._num_actions
+
+    @property
+    def num_observations(self) -> int:
+        return self._num_observations
+
+    @property
+    def num_states(self) -> int:
+        return self._num_states
+
+    @property
+    def num_agents(self) -> int:
+        return self._num_agents
+
+    def set_is_extension(self, is_extension) -> None:
+        self.is_extension = is_extension
+
+    def ensure_tensor(self, var) -> torch.Tensor:
+        if isinstance(var, torch.Tensor):
+            return var
+        if isinstance(var, np.ndarray):
+            return torch.from_numpy(var).to(device=self._device)
+        if isinstance(var, list):
+            return torch.tensor(var, device=self._device)
+        raise TypeError("Unsupported type for conversion to Tensor")

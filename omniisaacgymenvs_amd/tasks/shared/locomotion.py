@@ -1,0 +1,314 @@
+"""LocomotionTask -- host-side mirror of the reference class
+(/root/reference/omniisaacgymenvs/tasks/shared/locomotion.py:42-211) whose arithmetic runs in
+liboige_hip.so (csrc/locomotion.hip) through the C ABI of include/oige_hip.h.
+
+Same method names, argument meaning and buffer contract as the reference:
+``get_observations / pre_physics_step / reset_idx / post_reset / calculate_metrics / is_done``,
+plus a fused ``post_physics_step`` (one launch: progress, obs, reward, done in the
+rl_task.py:289-295 order).  There is no torch/CPU fallback: without the HIP library or a ROCm
+device every method raises.
+
+Two reset paths:
+  * ``reset_idx(env_ids)`` draws with torch exactly like the reference (two ``torch.rand``
+    of shape (n, D), :137 and :139) and hands the draws to the kernel -> same numbers as the
+    reference for the same torch RNG state;
+  * ``pre_physics_step`` (default ``sync_free=True``) never reads ``len(ids)`` on the host: ids
+    are compacted on the device and the draws come from an in-kernel Philox4x32-10 keyed by
+    (seed, step, env id).  ``sync_free=False`` reproduces the reference's flow (host count,
+    torch draws).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from abc import abstractmethod
+
+import torch
+
+from ... import _lib
+from ..base.rl_task import RLTask
+
+
+class LocomotionTask(RLTask):
+    # overridden by AntLocomotionTask / HumanoidLocomotionTask
+    _limit_cost_kind = 0
+    _num_sensors = 0
+
+    def __init__(self, name, env, offset=None) -> None:
+        LocomotionTask.update_config(self)
+        self.fused = True        # post_physics_step as one kernel
+        self.sync_free = True    # pre_physics_step without the host read of len(reset_env_ids)
+        self.materialize_vecs = True  # write up_vec / heading_vec back (locomotion.py:90-91)
+        self._step_count = 0
+        RLTask.__init__(self, name, env)
+
+    def update_config(self):
+        e = self._task_cfg["env"]
+        self._num_envs = e["numEnvs"]
+        self._env_spacing = e["envSpacing"]
+        self._max_episode_length = e["episodeLength"]
+        self.dof_vel_scale = e["dofVelocityScale"]
+        self.angular_velocity_scale = e["angularVelocityScale"]
+        self.contact_force_scale = e["contactForceScale"]
+        self.power_scale = e["powerScale"]
+        self.heading_weight = e["headingWeight"]
+        self.up_weight = e["upWeight"]
+        self.actions_cost_scale = e["actionsCost"]
+        self.energy_cost_scale = e["energyCost"]
+        self.joints_at_limit_cost_scale = e["jointsAtLimitCost"]
+        self.death_cost = e["deathCost"]
+        self.termination_height = e["terminationHeight"]
+        self.alive_reward_scale = e["alive_reward_scale"]
+
+    @abstractmethod
+    def set_up_scene(self, scene) -> None:
+        pass
+
+    @abstractmethod
+    def get_robot(self):
+        pass
+
+    # ------------------------------------------------------------------ C-ABI argument blocks
+    def _params(self) -> _lib.LocomotionParams:
+        """Rebuilt on demand so edits to the public scalars (e.g. ``task.heading_weight``) take effect."""
+        p = _lib.LocomotionParams()
+        d = self._robots.num_dof
+        p.num_dof, p.num_sensors, p.limit_cost_kind = d, self._num_sensors, self._limit_cost_kind
+        p.dt = self.dt
+        p.dof_vel_scale = self.dof_vel_scale
+        p.contact_force_scale = self.contact_force_scale
+        p.angular_velocity_scale = self.angular_velocity_scale
+        p.heading_weight = self.heading_weight
+        p.up_weight = self.up_weight
+        p.actions_cost_scale = self.actions_cost_scale
+        p.energy_cost_scale = self.energy_cost_scale
+        p.joints_at_limit_cost_scale = self.joints_at_limit_cost_scale
+        p.death_cost = self.death_cost
+        p.termination_height = self.termination_height
+        p.alive_reward_scale = self.alive_reward_scale
+        p.max_episode_length = float(self._max_episode_length)
+        p.power_scale = self.power_scale
+        p.clip_actions = float(min(self.clip_actions, 3.0e38))
+        c = self._host_consts
+        p.target[:] = c["target"]
+        p.inv_start_rot[:] = c["inv_start_rot"]
+        p.basis_vec0[:] = c["basis_vec0"]
+        p.basis_vec1[:] = c["basis_vec1"]
+        for name in ("dof_limits_lower", "dof_limits_upper", "joint_gears", "motor_effort_ratio"):
+            arr = getattr(p, name)
+            vals = c[name]
+            for j in range(d):
+                arr[j] = vals[j]
+        return p
+
+    def _refresh_host_consts(self) -> None:
+        """Row 0 of the per-env-constant tensors + the (D,) tables, read to the host once."""
+        self._host_consts = {
+            "target": self.targets[0].tolist(),
+            "inv_start_rot": self.inv_start_rot[0].tolist(),
+            "basis_vec0": self.basis_vec0[0].tolist(),
+            "basis_vec1": self.basis_vec1[0].tolist(),
+            "dof_limits_lower": self.dof_limits_lower.tolist(),
+            "dof_limits_upper": self.dof_limits_upper.tolist(),
+            "joint_gears": self.joint_gears.tolist(),
+            "motor_effort_ratio": self.motor_effort_ratio.tolist(),
+        }
+
+    def _buffers(self) -> _lib.LocomotionBuffers:
+        n, d = self._num_envs, self._robots.num_dof
+        rq = _lib.require_device_tensor
+        rq(self.obs_buf, torch.float32, (n, self._num_observations), "obs_buf")
+        rq(self.rew_buf, torch.float32, (n,), "rew_buf")
+        rq(self.reset_buf, torch.int64, (n,), "reset_buf")
+        rq(self.progress_buf, torch.int64, (n,), "progress_buf")
+        rq(self.potentials, torch.float32, (n,), "potentials")
+        rq(self.prev_potentials, torch.float32, (n,), "prev_potentials")
+        rq(self.actions, torch.float32, (n, d), "actions")
+        b = _lib.LocomotionBuffers()
+        b.obs_buf, b.rew_buf = self.obs_buf.data_ptr(), self.rew_buf.data_ptr()
+        b.reset_buf, b.progress_buf = self.reset_buf.data_ptr(), self.progress_buf.data_ptr()
+        b.potentials, b.prev_potentials = self.potentials.data_ptr(), self.prev_potentials.data_ptr()
+        if self.materialize_vecs:
+            rq(self.up_vec, torch.float32, (n, 3), "up_vec")
+            rq(self.heading_vec, torch.float32, (n, 3), "heading_vec")
+            b.up_vec, b.heading_vec = self.up_vec.data_ptr(), self.heading_vec.data_ptr()
+        b.actions = self.actions.data_ptr()
+        b.reset_workspace = self._reset_workspace.data_ptr()
+        return b
+
+    def _state(self) -> _lib.LocomotionState:
+        n, d = self._num_envs, self._robots.num_dof
+        torso_position, torso_rotation = self._robots.get_world_poses(clone=False)
+        velocities = self._robots.get_velocities(clone=False)
+        dof_pos = self._robots.get_joint_positions(clone=False)
+        dof_vel = self._robots.get_joint_velocities(clone=False)
+        # force sensors attached to the feet
+        sensor_force_torques = self._robots.get_measured_joint_forces(joint_indices=self._sensor_indices)
+        rq = _lib.require_device_tensor
+        rq(torso_position, torch.float32, (n, 3), "torso_position")
+        rq(torso_rotation, torch.float32, (n, 4), "torso_rotation")
+        rq(velocities, torch.float32, (n, 6), "velocities")
+        rq(dof_pos, torch.float32, (n, d), "dof_pos")
+        rq(dof_vel, torch.float32, (n, d), "dof_vel")
+        rq(sensor_force_torques, torch.float32, (n, self._num_sensors, 6), "sensor_force_torques")
+        s = _lib.LocomotionState()
+        s.torso_position, s.torso_rotation = torso_position.data_ptr(), torso_rotation.data_ptr()
+        s.velocities = velocities.data_ptr()
+        s.dof_pos, s.dof_vel = dof_pos.data_ptr(), dof_vel.data_ptr()
+        s.sensor_force_torques = sensor_force_torques.data_ptr()
+        self._live_state = (torso_position, torso_rotation, velocities, dof_pos, dof_vel, sensor_force_torques)
+        return s
+
+    def _post(self, stages: int) -> None:
+        state = self._state() if stages & _lib.STAGE_OBS else None
+        p, b = self._params(), self._buffers()
+        rc = _lib.load().oige_locomotion_post_physics(
+            C.byref(p), C.byref(state) if state is not None else None, C.byref(b), self._num_envs, stages,
+            _lib.current_stream(self.obs_buf.device),
+        )
+        _lib.check(rc, "oige_locomotion_post_physics")
+        if stages & _lib.STAGE_DONE:
+            self._counts_key = (self.reset_buf.data_ptr(), self.reset_buf._version)
+
+    # ------------------------------------------------------------------ RLTask methods
+    def get_observations(self) -> dict:
+        self._post(_lib.STAGE_OBS)
+        return {self._robots.name: {"obs_buf": self.obs_buf}}
+
+    def calculate_metrics(self) -> None:
+        self._post(_lib.STAGE_METRICS)
+
+    def is_done(self) -> None:
+        self._post(_lib.STAGE_DONE)
+
+    def post_physics_step(self):
+        if not self.fused:
+            return RLTask.post_physics_step(self)
+        if self._env.world.is_playing():
+            self._post(_lib.STAGE_ALL)
+            self.get_states()
+            self.get_extras()
+        else:
+            self._post(_lib.STAGE_PROGRESS)
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def _reset_io(self, u_pos=None, u_vel=None) -> _lib.LocomotionResetIO:
+        r = _lib.LocomotionResetIO()
+        r.initial_root_pos = self.initial_root_pos.data_ptr()
+        r.initial_root_rot = self.initial_root_rot.data_ptr()
+        r.initial_dof_pos = self.initial_dof_pos.data_ptr()
+        if u_pos is not None:
+            r.u_pos, r.u_vel = u_pos.data_ptr(), u_vel.data_ptr()
+        r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
+        r.step = self._step_count
+        o = self._reset_out
+        r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
+        r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
+        r.root_pos_out, r.root_rot_out, r.root_vel_out = (
+            o["root_pos"].data_ptr(), o["root_rot"].data_ptr(), o["root_vel"].data_ptr())
+        return r
+
+    def _apply_reset_writes(self, n=None) -> None:
+        """Hand the compacted rows to the view setters (:145-149).  ``n`` None -> device count."""
+        o = self._reset_out
+        if n is None:
+            kw = dict(indices=o["env_ids"], count=o["count"])
+            sl = slice(None)
+        else:
+            kw = dict(indices=o["env_ids"][:n])
+            sl = slice(0, n)
+        self._robots.set_joint_positions(o["dof_pos"][sl], **kw)
+        self._robots.set_joint_velocities(o["dof_vel"][sl], **kw)
+        self._robots.set_world_poses(o["root_pos"][sl], o["root_rot"][sl], **kw)
+        self._robots.set_velocities(o["root_vel"][sl], **kw)
+
+    def pre_physics_step(self, actions) -> None:
+        if not self.world.is_playing():
+            return
+        n, d = self._num_envs, self._robots.num_dof
+        actions = actions.to(self._device)
+        _lib.require_device_tensor(actions, torch.float32, (n, d), "actions")
+        self._step_count += 1
+        flags = 0
+        if not self.sync_free:
+            # the reference's flow: host-visible id list, torch-drawn noise (:121-123)
+            o = self._reset_out
+            _lib.compact(self.reset_buf, self._reset_workspace, o["env_ids"], o["count"])
+            num = int(o["count"].item())
+            if num > 0:
+                self.reset_idx(o["env_ids"][:num].clone())
+        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key:
+            flags |= _lib.PRE_COUNTS_VALID  # the DONE stage's tile counts still describe reset_buf
+        p, b, r = self._params(), self._buffers(), self._reset_io()
+        rc = _lib.load().oige_locomotion_pre_physics(
+            C.byref(p), actions.data_ptr(), C.byref(b), C.byref(r), self.actions.data_ptr(), self._forces.data_ptr(),
+            n, flags, _lib.current_stream(self.obs_buf.device),
+        )
+        _lib.check(rc, "oige_locomotion_pre_physics")
+        self._counts_key = None
+        if self.sync_free:
+            self._apply_reset_writes(None)
+        # applies joint torques
+        self._robots.set_joint_efforts(self._forces, indices=self._all_indices)
+
+    def reset_idx(self, env_ids):
+        num_resets = len(env_ids)
+        if num_resets == 0:
+            return
+        d = self._robots.num_dof
+        env_ids = env_ids.to(device=self._device, dtype=torch.int64).contiguous()
+        # randomize DOF positions and velocities: same two draws, same order as the reference
+        u_pos = torch.rand(num_resets, d, device=self._device)
+        u_vel = torch.rand(num_resets, d, device=self._device)
+        o = self._reset_out
+        o["env_ids"][:num_resets] = env_ids
+        o["count"].fill_(num_resets)
+        p, b, r = self._params(), self._buffers(), self._reset_io(u_pos, u_vel)
+        rc = _lib.load().oige_locomotion_reset_idx(
+            C.byref(p), C.byref(b), C.byref(r), self._num_envs, num_resets, _lib.current_stream(self.obs_buf.device)
+        )
+        _lib.check(rc, "oige_locomotion_reset_idx")
+        self._counts_key = None
+        self._apply_reset_writes(num_resets)
+
+    def post_reset(self):
+        self._robots = self.get_robot()
+        self.initial_root_pos, self.initial_root_rot = self._robots.get_world_poses()
+        self.initial_dof_pos = self._robots.get_joint_positions()
+        dev, n, d = self._device, self.num_envs, self._robots.num_dof
+
+        # initialize some data used later on (:168-184)
+        self.start_rotation = torch.tensor([1, 0, 0, 0], device=dev, dtype=torch.float32)
+        self.up_vec = torch.tensor([0, 0, 1], dtype=torch.float32, device=dev).repeat((n, 1))
+        self.heading_vec = torch.tensor([1, 0, 0], dtype=torch.float32, device=dev).repeat((n, 1))
+        inv = self.start_rotation.clone()
+        inv[1:] = -inv[1:]  # quat_conjugate
+        self.inv_start_rot = inv.repeat((n, 1))
+        self.basis_vec0 = self.heading_vec.clone()
+        self.basis_vec1 = self.up_vec.clone()
+        self.targets = torch.tensor([1000, 0, 0], dtype=torch.float32, device=dev).repeat((n, 1))
+        self.target_dirs = torch.tensor([1, 0, 0], dtype=torch.float32, device=dev).repeat((n, 1))
+        self.dt = 1.0 / 60.0
+        self.potentials = torch.tensor([-1000.0 / self.dt], dtype=torch.float32, device=dev).repeat(n)
+        self.prev_potentials = self.potentials.clone()
+        self.actions = torch.zeros((n, self.num_actions), device=dev)
+
+        # device-side scratch of the HIP path (never resized)
+        f = dict(dtype=torch.float32, device=dev)
+        self._forces = torch.zeros((n, d), **f)
+        self._reset_workspace = _lib.new_workspace(n, dev)
+        self._reset_out = {
+            "env_ids": torch.zeros(n, dtype=torch.int64, device=dev),
+            "count": torch.zeros(1, dtype=torch.int64, device=dev),
+            "dof_pos": torch.zeros((n, d), **f),
+            "dof_vel": torch.zeros((n, d), **f),
+            "root_pos": torch.zeros((n, 3), **f),
+            "root_rot": torch.zeros((n, 4), **f),
+            "root_vel": torch.zeros((n, 6), **f),
+        }
+        self._all_indices = torch.arange(self._robots.count, dtype=torch.int32, device=dev)
+        self._counts_key = None
+        self._refresh_host_consts()
+
+        # randomize all envs
+        indices = torch.arange(self._robots.count, dtype=torch.int64, device=dev)
+        self.reset_idx(indices)

@@ -1,0 +1,104 @@
+"""Task / global configuration without hydra (hydra & omegaconf are not part of this path).
+
+The reference reads its scalars from ``cfg/task/<Task>.yaml`` through
+``sim_config.task_config["env"][...]`` (e.g. tasks/shared/locomotion.py:50-65).  The
+dictionaries below carry the same keys and the YAML's values (file:line cited), so the task
+classes read them exactly the way the reference does.  ``SimConfig`` is the small slice of
+utils/config_utils/sim_config.py the task constructors touch: ``.config`` and ``.task_config``.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Dict, Optional
+
+
+def global_config(**overrides: Any) -> Dict[str, Any]:
+    """cfg/config.yaml globals the hot path reads (rl_task.py:72-77,104; vec_env_rlgames.py:58-68)."""
+    cfg: Dict[str, Any] = {
+        "seed": 42,
+        "test": False,
+        "sim_device": "cuda:0",
+        "rl_device": "cuda:0",
+        "headless": True,
+        "enable_livestream": False,
+        "enable_recording": False,
+        "recording_interval": 2000,
+        "recording_length": 100,
+        "multi_gpu": False,
+    }
+    cfg.update(overrides)
+    return cfg
+
+
+_SIM = {"dt": 0.0083, "add_ground_plane": True, "add_distant_light": False, "enable_cameras": False}
+
+TASK_DEFAULTS: Dict[str, Dict[str, Any]] = {
+    # cfg/task/Cartpole.yaml:7-14
+    "Cartpole": {
+        "name": "Cartpole",
+        "env": {
+            "numEnvs": 512, "envSpacing": 4.0, "resetDist": 3.0, "maxEffort": 400.0,
+            "clipObservations": 5.0, "clipActions": 1.0, "controlFrequencyInv": 2,
+        },
+        "sim": dict(_SIM),
+    },
+    # cfg/task/Ant.yaml:8-32
+    "Ant": {
+        "name": "Ant",
+        "env": {
+            "numEnvs": 4096, "envSpacing": 5, "episodeLength": 1000, "enableDebugVis": False,
+            "clipActions": 1.0, "powerScale": 0.5, "controlFrequencyInv": 2,
+            "headingWeight": 0.5, "upWeight": 0.1,
+            "actionsCost": 0.005, "energyCost": 0.05, "dofVelocityScale": 0.2, "angularVelocityScale": 1.0,
+            "contactForceScale": 0.1, "jointsAtLimitCost": 0.1, "deathCost": -2.0, "terminationHeight": 0.31,
+            "alive_reward_scale": 0.5,
+        },
+        "sim": dict(_SIM),
+    },
+    # cfg/task/Humanoid.yaml:8-32
+    "Humanoid": {
+        "name": "Humanoid",
+        "env": {
+            "numEnvs": 4096, "envSpacing": 5, "episodeLength": 1000, "enableDebugVis": False,
+            "clipActions": 1.0, "powerScale": 1.0, "controlFrequencyInv": 2,
+            "headingWeight": 0.5, "upWeight": 0.1,
+            "actionsCost": 0.01, "energyCost": 0.05, "dofVelocityScale": 0.1, "angularVelocityScale": 0.25,
+            "contactForceScale": 0.01, "jointsAtLimitCost": 0.25, "deathCost": -1.0, "terminationHeight": 0.8,
+            "alive_reward_scale": 2.0,
+        },
+        "sim": dict(_SIM),
+    },
+}
+
+
+def task_config(name: str, num_envs: Optional[int] = None, **env_overrides: Any) -> Dict[str, Any]:
+    cfg = copy.deepcopy(TASK_DEFAULTS[name])
+    if num_envs is not None:
+        cfg["env"]["numEnvs"] = int(num_envs)
+    cfg["env"].update(env_overrides)
+    return cfg
+
+
+class SimConfig:
+    """``sim_config.config`` / ``sim_config.task_config`` as the task constructors use them
+    (tasks/ant.py:52-55).  PhysX parameter parsing (the rest of the reference class) is out of scope."""
+
+    def __init__(self, config: Optional[Dict[str, Any]] = None, task_config_: Optional[Dict[str, Any]] = None):
+        self._config = config if config is not None else global_config()
+        self._task_config = task_config_ if task_config_ is not None else {}
+        self._config.setdefault("task", self._task_config)
+
+    @property
+    def config(self) -> Dict[str, Any]:
+        return self._config
+
+    @property
+    def task_config(self) -> Dict[str, Any]:
+        return self._task_config
+
+    # no-ops kept so reference-style task code can call them
+    def apply_articulation_settings(self, *a, **k) -> None:
+        return None
+
+    def parse_actor_config(self, actor_name: str) -> Dict[str, Any]:
+        return {}

@@ -1,0 +1,107 @@
+"""Observation / action noise of the reference's domain randomisation
+(/root/reference/omniisaacgymenvs/utils/domain_randomization/randomize.py:215-410), the part of
+``Randomizer`` that is task math.  Physics-parameter randomisation through
+``omni.replicator.isaac`` (:151-213, :412-771) mutates PhysX state and is out of scope.
+
+The arithmetic runs in liboige_hip.so (csrc/dr_noise.hip) -- see ``apply_*_randomization``.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional
+
+import numpy as np
+import torch
+
+_NEEDED_RESET = ("operation", "distribution", "distribution_parameters")
+_NEEDED_INTERVAL = ("frequency_interval", "operation", "distribution", "distribution_parameters")
+
+
+class Randomizer:
+    def __init__(self, main_config: Dict[str, Any], task_config: Dict[str, Any]):
+        self._cfg = task_config
+        self._config = main_config
+        self.randomize = False
+        dr_config = self._cfg.get("domain_randomization", None)
+        self.distributions: Dict[str, Any] = dict()
+        self.active_domain_randomizations: Dict[Any, Any] = dict()
+        self._observations_dr_params: Optional[Dict[str, Any]] = None
+        self._actions_dr_params: Optional[Dict[str, Any]] = None
+        if dr_config is not None:
+            randomize = dr_config.get("randomize", False)
+            randomization_params = dr_config.get("randomization_params", None)
+            if randomize and randomization_params is not None:
+                self.randomize = True
+                self.min_frequency = dr_config.get("min_frequency", 1)
+
+    # ------------------------------------------------------------------ setup (:151-281)
+    def set_up_domain_randomization(self, task) -> None:
+        if not self.randomize:
+            dr_config = self._cfg.get("domain_randomization", None)
+            if dr_config is None:
+                raise ValueError("No domain randomization parameters are specified in the task yaml config file")
+            print("Domain randomization will not be applied.")
+            return
+        params = self._cfg["domain_randomization"]["randomization_params"]
+        for opt in params.keys():
+            if opt == "observations":
+                self._set_up_observations_randomization(task)
+            elif opt == "actions":
+                self._set_up_actions_randomization(task)
+            # "simulation" / "rigid_prim_views" / "articulation_views": PhysX-side, delegated
+
+    def _validate(self, params: Optional[Dict[str, Any]], what: str) -> Dict[str, Any]:
+        if params is None:
+            raise ValueError(f"{what.capitalize()} randomization parameters are not provided.")
+        if "on_reset" in params and not set(_NEEDED_RESET).issubset(params["on_reset"].keys()):
+            raise ValueError(
+                f"Please ensure the following {what} on_reset randomization parameters are provided: "
+                "operation, distribution, distribution_parameters."
+            )
+        if "on_interval" in params and not set(_NEEDED_INTERVAL).issubset(params["on_interval"].keys()):
+            raise ValueError(
+                f"Please ensure the following {what} on_interval randomization parameters are provided: "
+                "frequency_interval, operation, distribution, distribution_parameters."
+            )
+        for when in ("on_reset", "on_interval"):
+            if when in params:
+                self.active_domain_randomizations[(what, when)] = np.array(params[when]["distribution_parameters"])
+        return params
+
+    def _set_up_observations_randomization(self, task) -> None:
+        task.randomize_observations = True
+        self._observations_dr_params = self._validate(
+            self._cfg["domain_randomization"]["randomization_params"]["observations"], "observations"
+        )
+        n, dev = self._cfg["env"]["numEnvs"], self._config["rl_device"]
+        self._observations_counter_buffer = torch.zeros((n), dtype=torch.int, device=dev)
+        self._observations_correlated_noise = torch.zeros((n, task.num_observations), device=dev)
+        self._observations_step = 0
+
+    def _set_up_actions_randomization(self, task) -> None:
+        task.randomize_actions = True
+        self._actions_dr_params = self._validate(
+            self._cfg["domain_randomization"]["randomization_params"]["actions"], "actions"
+        )
+        n, dev = self._cfg["env"]["numEnvs"], self._config["rl_device"]
+        self._actions_counter_buffer = torch.zeros((n), dtype=torch.int, device=dev)
+        self._actions_correlated_noise = torch.zeros((n, task.num_actions), device=dev)
+        self._actions_step = 0
+
+    # ------------------------------------------------------------------ per-step noise (:283-410)
+    def apply_observations_randomization(self, observations, reset_buf):
+        from . import noise_hip
+
+        self._observations_step += 1
+        return noise_hip.apply(
+            observations, reset_buf, self._observations_counter_buffer, self._observations_correlated_noise,
+            self._observations_dr_params, seed=int(self._config.get("seed", 0)), stream_id=0, step=self._observations_step,
+        )
+
+    def apply_actions_randomization(self, actions, reset_buf):
+        from . import noise_hip
+
+        self._actions_step += 1
+        return noise_hip.apply(
+            actions, reset_buf, self._actions_counter_buffer, self._actions_correlated_noise,
+            self._actions_dr_params, seed=int(self._config.get("seed", 0)), stream_id=1, step=self._actions_step,
+        )
