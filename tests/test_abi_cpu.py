@@ -1,0 +1,74 @@
+"""CPU: liboige_hip.so loads without a GPU, exports every symbol include/oige_hip.h declares, and
+the ctypes structs of omniisaacgymenvs_amd/_lib.py have the layout the C compiler gives the header."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+from omniisaacgymenvs_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "oige_hip.h")
+
+
+def _declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(oige_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared_symbols()
+    assert len(names) >= 12
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/oige_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in _lib.py"
+    assert lib.oige_version() == 1
+    assert lib.oige_num_tiles(65) == 2 and lib.oige_workspace_ints(257) == 8 + 2 + 1
+
+
+def test_struct_layouts_match_the_c_header(tmp_path):
+    structs = {k: v for k, v in vars(_lib).items() if isinstance(v, type) and issubclass(v, ctypes.Structure)
+               and v is not ctypes.Structure}
+    cname = lambda n: "oige_" + re.sub(r"(?<!^)(?=[A-Z])", "_", n).lower().replace("reset_i_o", "reset_io")
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "oige_hip.h"\nint main(void){\n'
+    for n in sorted(structs):
+        src += f'  printf("{n} %zu\\n", sizeof({cname(n)}));\n'
+    src += '  printf("lower %zu\\n", offsetof(oige_locomotion_params, dof_limits_lower));\n'
+    src += '  printf("count %zu\\n", offsetof(oige_locomotion_reset_io, count));\n  return 0;\n}\n'
+    c = tmp_path / "sz.c"
+    c.write_text(src)
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n, cls in structs.items():
+        assert int(out[n]) == ctypes.sizeof(cls), f"{n}: C {out[n]} vs ctypes {ctypes.sizeof(cls)}"
+    assert int(out["lower"]) == _lib.LocomotionParams.dof_limits_lower.offset
+    assert int(out["count"]) == _lib.LocomotionResetIO.count.offset
+
+
+def test_bad_arguments_fail_loudly_without_a_gpu():
+    lib = _lib.load()
+    p = _lib.LocomotionParams()
+    p.num_dof, p.num_sensors = 5, 1  # not a built configuration
+    rc = lib.oige_locomotion_post_physics(ctypes.byref(p), None, None, 10, _lib.STAGE_ALL, None)
+    assert rc == -1 and b"unsupported" in lib.oige_last_error()
+    with pytest.raises(_lib.OigeError):
+        _lib.check(rc, "oige_locomotion_post_physics")
+    import torch
+    with pytest.raises(_lib.OigeError, match="no CPU fallback"):
+        _lib.require_device_tensor(torch.zeros(4), torch.float32, (4,), "obs_buf")
+
+
+def test_product_path_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under omniisaacgymenvs_amd/ may import it."""
+    pkg = os.path.join(ROOT, "omniisaacgymenvs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
