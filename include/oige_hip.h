@@ -168,6 +168,143 @@ int oige_locomotion_reset_idx(const oige_locomotion_params* params, const oige_l
                               const oige_locomotion_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
                               oige_stream_t stream);
 
+/* ------------------------------------------------------------------ ShadowHand / in-hand manipulation
+ * tasks/shared/in_hand_manipulation.py (reward, resets, action scaling) and
+ * tasks/shadow_hand.py (observation packers).  Scalars: update_config (:63-97), ShadowHand.yaml.  */
+#define OIGE_HAND_OBS_OPENAI 0 /* 42 cols, shadow_hand.py:162-165 */
+#define OIGE_HAND_OBS_FULL 2   /* 157 cols, shadow_hand.py:198-217 */
+#define OIGE_HAND_DOFS 24
+#define OIGE_HAND_ACTIONS 20
+#define OIGE_HAND_FINGERTIPS 5
+#define OIGE_HAND_STATES 187   /* asymmetric full_state states_buf, shadow_hand.py:220-262 */
+
+typedef struct oige_hand_params {
+  int32_t obs_type;                   /* OIGE_HAND_OBS_* */
+  int32_t asymmetric_obs;             /* also fill states_buf (N,187) */
+  int32_t max_consecutive_successes;
+  int32_t use_relative_control;
+  float max_episode_length;           /* float, as compute_hand_reward's signature (:464) */
+  float dist_reward_scale;
+  float rot_reward_scale;
+  float rot_eps;
+  float action_penalty_scale;
+  float success_tolerance;
+  float reach_goal_bonus;
+  float fall_dist;
+  float fall_penalty;
+  float av_factor;
+  float vel_obs_scale;
+  float force_torque_obs_scale;       /* 10.0, shadow_hand.py:84 */
+  float hand_dof_speed_scale;
+  float dt;                           /* 1/60, in_hand_manipulation.py:92 */
+  float act_moving_average;
+  float reset_position_noise;
+  float reset_dof_pos_noise;
+  float reset_dof_vel_noise;
+  float clip_actions;                 /* with OIGE_PRE_CLAMP_ACTIONS */
+  float one_minus_act_moving_average; /* (float)(1.0 - actionsMovingAverage), folded in double like Python (:350) */
+  float dof_speed_scale_dt;           /* (float)(dofSpeedScale * dt), folded in double like Python (:335) */
+  float reserved0[3];
+  float goal_displacement[3];         /* (-0.2,-0.06,0.12), :111 */
+  float reserved1;
+  float dof_lower[OIGE_MAX_DOF];
+  float dof_upper[OIGE_MAX_DOF];
+  float dof_default_pos[OIGE_MAX_DOF];
+  float dof_default_vel[OIGE_MAX_DOF];
+  int32_t actuated_dof_indices[OIGE_MAX_DOF]; /* 20 sorted indices, views/shadow_hand_view.py:59-84 */
+} oige_hand_params;
+
+/* View getters of shadow_hand.py:121-135 (world frame, read-only: the reference's in-place
+ * `-= env_pos` on these buffers is NOT reproduced, the subtraction happens in registers). */
+typedef struct oige_hand_state {
+  const float* object_pos;           /* (N,3) */
+  const float* object_rot;           /* (N,4) */
+  const float* object_velocities;    /* (N,6) */
+  const float* fingertip_pos;        /* (5N,3) */
+  const float* fingertip_rot;        /* (5N,4) */
+  const float* fingertip_velocities; /* (5N,6) */
+  const float* hand_dof_pos;         /* (N,24) */
+  const float* hand_dof_vel;         /* (N,24) */
+  const float* vec_sensor;           /* (N,5,6); may be NULL unless asymmetric_obs */
+  const float* env_pos;              /* (N,3) RLTask._env_pos */
+} oige_hand_state;
+
+typedef struct oige_hand_buffers {
+  float* obs_buf;                /* (N,42|157) */
+  float* states_buf;             /* (N,187) or NULL */
+  float* rew_buf;                /* (N,) */
+  int64_t* reset_buf;            /* (N,) */
+  int64_t* reset_goal_buf;       /* (N,) */
+  int64_t* progress_buf;         /* (N,) */
+  float* successes;              /* (N,) float, accumulates int64 goal_resets (:500) */
+  float* consecutive_successes;  /* (1,) */
+  float* goal_pos;               /* (N,3) env-local */
+  float* goal_rot;               /* (N,4) */
+  const float* actions;          /* (N,20) the task's self.actions */
+  float* prev_targets;           /* (N,24) */
+  float* cur_targets;            /* (N,24) */
+  int64_t* randomization_buf;    /* (N,) or NULL: += 1 per calculate_metrics (:297) */
+  int32_t* reset_workspace;      /* oige_workspace_ints(N): tile counts of reset_buf */
+  int32_t* goal_workspace;       /* oige_workspace_ints(N): tile counts of reset_goal_buf */
+  float* reduce_workspace;       /* 2*oige_num_tiles(N) floats: per-tile (num_resets, sum successes*resets) */
+} oige_hand_buffers;
+
+/* post_physics_step: progress += 1 (rl_task.py:289), get_observations (shadow_hand.py:120-152),
+ * calculate_metrics = compute_hand_reward (in_hand_manipulation.py:263-297, jit :457-531) including
+ * the two global sums that update consecutive_successes (deterministic two-stage reduction).
+ * is_done is a no-op in the reference (:374): OIGE_STAGE_DONE is accepted and ignored.        */
+int oige_hand_post_physics(const oige_hand_params* params, const oige_hand_state* state,
+                           const oige_hand_buffers* buffers, int64_t num_envs, uint32_t stages,
+                           oige_stream_t stream);
+
+/* Draw layout for the exact-parity path (all U(-1,1), i.e. torch_rand_float(-1, 1, ...) outputs):
+ *   u_goal  (ng,4)  reset_target_pose(goal_env_ids)                      (:380)
+ *   u_reset (ne,53) reset_idx(env_ids)                                   (:399)
+ *   u_reset_goal (ne,4) the nested reset_target_pose(env_ids)            (:401 -> :380)
+ * NULL -> in-kernel Philox keyed by (seed, step, env id, stream).                             */
+typedef struct oige_hand_reset_io {
+  const float* object_init_pos;  /* (N,3) env-local (:236-237) */
+  const float* goal_init_pos;    /* (N,3) (:246) */
+  const float* env_pos;          /* (N,3) */
+  const float* u_goal;
+  const float* u_reset;
+  const float* u_reset_goal;
+  uint64_t seed;
+  uint64_t step;
+  /* goal-only resets (reset_target_pose of goal_env_ids): rows for _goals.set_world_poses */
+  int64_t* goal_ids;             /* out (N,) ascending == reset_goal_buf.nonzero() */
+  int64_t* goal_count;           /* out device scalar */
+  float* goal_world_pos_out;     /* out (ng,3) goal_pos + displacement + env_pos */
+  float* goal_rot_out;           /* out (ng,4) */
+  /* full resets (reset_idx of env_ids) */
+  int64_t* env_ids;              /* out (N,) ascending == reset_buf.nonzero() */
+  int64_t* count;                /* out device scalar */
+  float* r_goal_world_pos_out;   /* out (ne,3) */
+  float* r_goal_rot_out;         /* out (ne,4) */
+  float* object_pos_out;         /* out (ne,3) world */
+  float* object_rot_out;         /* out (ne,4) */
+  float* object_vel_out;         /* out (ne,6) zeros */
+  float* dof_pos_out;            /* out (ne,24) also the position targets (:433-436) */
+  float* dof_vel_out;            /* out (ne,24) */
+} oige_hand_reset_io;
+
+/* pre_physics_step (:314-362): both compactions, reset_target_pose of goal ids, reset_idx of env
+ * ids, actions clone, scale/EMA/clamp (or relative control) into cur_targets/prev_targets;
+ * targets_out (N,20) = cur_targets[:, actuated] for set_joint_position_targets (:360-362).     */
+int oige_hand_pre_physics(const oige_hand_params* params, const float* actions_in,
+                          const oige_hand_buffers* buffers, const oige_hand_reset_io* reset_io,
+                          float* actions_out, float* targets_out, int64_t num_envs, uint32_t flags,
+                          oige_stream_t stream);
+
+/* reset_idx(env_ids) / reset_target_pose(env_ids) with caller-provided ids (device count scalar in
+ * reset_io->count / ->goal_count, ids in ->env_ids / ->goal_ids).                                */
+int oige_hand_reset_idx(const oige_hand_params* params, const oige_hand_buffers* buffers,
+                        const oige_hand_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                        oige_stream_t stream);
+int oige_hand_reset_target_pose(const oige_hand_params* params, const oige_hand_buffers* buffers,
+                                const oige_hand_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                                oige_stream_t stream);
+
 /* ------------------------------------------------------------------ Cartpole
  * tasks/cartpole.py:91-164.                                                                 */
 typedef struct oige_cartpole_params {

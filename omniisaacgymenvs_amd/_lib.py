@@ -73,6 +73,50 @@ class CartpoleResetIO(C.Structure):
                 ("dof_pos_out", _fp), ("dof_vel_out", _fp)]
 
 
+class HandParams(C.Structure):
+    _fields_ = [
+        ("obs_type", C.c_int32), ("asymmetric_obs", C.c_int32), ("max_consecutive_successes", C.c_int32),
+        ("use_relative_control", C.c_int32),
+        ("max_episode_length", _f), ("dist_reward_scale", _f), ("rot_reward_scale", _f), ("rot_eps", _f),
+        ("action_penalty_scale", _f), ("success_tolerance", _f), ("reach_goal_bonus", _f), ("fall_dist", _f),
+        ("fall_penalty", _f), ("av_factor", _f), ("vel_obs_scale", _f), ("force_torque_obs_scale", _f),
+        ("hand_dof_speed_scale", _f), ("dt", _f), ("act_moving_average", _f), ("reset_position_noise", _f),
+        ("reset_dof_pos_noise", _f), ("reset_dof_vel_noise", _f), ("clip_actions", _f),
+        ("one_minus_act_moving_average", _f), ("dof_speed_scale_dt", _f), ("reserved0", _f * 3),
+        ("goal_displacement", _f * 3), ("reserved1", _f),
+        ("dof_lower", _f * OIGE_MAX_DOF), ("dof_upper", _f * OIGE_MAX_DOF),
+        ("dof_default_pos", _f * OIGE_MAX_DOF), ("dof_default_vel", _f * OIGE_MAX_DOF),
+        ("actuated_dof_indices", C.c_int32 * OIGE_MAX_DOF),
+    ]
+
+
+class HandState(C.Structure):
+    _fields_ = [(n, _fp) for n in (
+        "object_pos", "object_rot", "object_velocities", "fingertip_pos", "fingertip_rot", "fingertip_velocities",
+        "hand_dof_pos", "hand_dof_vel", "vec_sensor", "env_pos")]
+
+
+class HandBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in (
+        "obs_buf", "states_buf", "rew_buf", "reset_buf", "reset_goal_buf", "progress_buf", "successes",
+        "consecutive_successes", "goal_pos", "goal_rot", "actions", "prev_targets", "cur_targets",
+        "randomization_buf", "reset_workspace", "goal_workspace", "reduce_workspace")]
+
+
+class HandResetIO(C.Structure):
+    _fields_ = [
+        ("object_init_pos", _fp), ("goal_init_pos", _fp), ("env_pos", _fp),
+        ("u_goal", _fp), ("u_reset", _fp), ("u_reset_goal", _fp),
+        ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("goal_ids", _fp), ("goal_count", _fp), ("goal_world_pos_out", _fp), ("goal_rot_out", _fp),
+        ("env_ids", _fp), ("count", _fp), ("r_goal_world_pos_out", _fp), ("r_goal_rot_out", _fp),
+        ("object_pos_out", _fp), ("object_rot_out", _fp), ("object_vel_out", _fp),
+        ("dof_pos_out", _fp), ("dof_vel_out", _fp),
+    ]
+
+HAND_OBS_OPENAI, HAND_OBS_FULL = 0, 2
+
+
 # name -> (restype, argtypes); every symbol include/oige_hip.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -94,6 +138,14 @@ SIGNATURES = {
                                             C.POINTER(CartpoleResetIO), _P, C.c_int64, C.c_uint32, _P]),
     "oige_cartpole_reset_idx": (C.c_int, [C.POINTER(CartpoleParams), C.POINTER(CartpoleBuffers),
                                           C.POINTER(CartpoleResetIO), C.c_int64, C.c_int64, _P]),
+    "oige_hand_post_physics": (C.c_int, [C.POINTER(HandParams), C.POINTER(HandState), C.POINTER(HandBuffers), C.c_int64,
+                                         C.c_uint32, _P]),
+    "oige_hand_pre_physics": (C.c_int, [C.POINTER(HandParams), _P, C.POINTER(HandBuffers), C.POINTER(HandResetIO), _P, _P,
+                                        C.c_int64, C.c_uint32, _P]),
+    "oige_hand_reset_idx": (C.c_int, [C.POINTER(HandParams), C.POINTER(HandBuffers), C.POINTER(HandResetIO), C.c_int64,
+                                      C.c_int64, _P]),
+    "oige_hand_reset_target_pose": (C.c_int, [C.POINTER(HandParams), C.POINTER(HandBuffers), C.POINTER(HandResetIO),
+                                              C.c_int64, C.c_int64, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -1,0 +1,687 @@
+// ShadowHand / in-hand manipulation per-step task math for gfx950 (MI355X).
+//
+// Replaces, behind the unchanged InHandManipulationTask / ShadowHandTask method contract:
+//   get_observations    tasks/shadow_hand.py:120-262 (openai 42 / full 157 obs, asymmetric states 187)
+//   calculate_metrics   tasks/shared/in_hand_manipulation.py:263-297, jit compute_hand_reward :457-531
+//   pre_physics_step    in_hand_manipulation.py:314-362
+//   reset_target_pose   :377-395, jit randomize_rotation :450-453
+//   reset_idx           :397-441
+//
+// post_physics: one workgroup of 256 threads (4 waves) owns one tile of 64 envs.  Every input
+// array's slice for the tile is one contiguous run, moved with lane-linear float4 loads and
+// transposed through LDS into the obs / states tiles, which stream back to HBM as contiguous
+// runs; wave 0 does the per-env quaternion / reward math in between.  HBM-bound: 1720 algorithmic
+// bytes per env-step for openai obs + asymmetric states.
+// The two global sums of compute_hand_reward (:522-523) are reduced deterministically: one
+// (count, sum) pair per tile from a fixed shuffle tree, then a single-workgroup pass in tile order.
+#include "oige_common.hpp"
+#include "oige_math.hpp"
+#include "oige_tile.hpp"
+
+namespace oige {
+
+constexpr int HD = OIGE_HAND_DOFS;        // 24
+constexpr int HA = OIGE_HAND_ACTIONS;     // 20
+constexpr int HF = OIGE_HAND_FINGERTIPS;  // 5
+constexpr int HS = OIGE_HAND_STATES;      // 187
+constexpr int HNT = 256;                  // threads per tile
+
+struct HandPost {
+  oige_hand_params p;
+  oige_hand_state s;
+  oige_hand_buffers b;
+  int64_t n;
+  uint32_t stages;
+  float max_len_minus_1;   // (float)((double)max_episode_length - 1.0)
+  float half_fall_penalty; // (float)(0.5 * (double)fall_penalty)
+};
+
+struct HandRewardOut {
+  float reward, successes;
+  int64_t resets, goal_resets, progress;
+};
+
+// compute_hand_reward for one env (:482-520)
+__device__ __forceinline__ HandRewardOut hand_reward(const HandPost& a, const f3 object_pos, const q4 object_rot,
+                                                     const f3 target_pos, const q4 target_rot, float action_penalty,
+                                                     int64_t reset_in, int64_t reset_goal_in, int64_t progress,
+                                                     float successes) {
+  const oige_hand_params& p = a.p;
+  const float goal_dist = norm3(f3{object_pos.x - target_pos.x, object_pos.y - target_pos.y, object_pos.z - target_pos.z});
+  const q4 qd = quat_mul(object_rot, quat_conjugate(target_rot));
+  float nv = norm3(f3{qd.x, qd.y, qd.z});
+  nv = (nv != nv) ? nv : (nv > 1.0f ? 1.0f : nv);  // torch.clamp(max=1.0)
+  const float rot_dist = 2.0f * asinf(nv);
+  const float ard = __builtin_fabsf(rot_dist);
+  const float dist_rew = goal_dist * p.dist_reward_scale;
+  const float rot_rew = (1.0f / (ard + p.rot_eps)) * p.rot_reward_scale;
+  float reward = (dist_rew + rot_rew) + action_penalty * p.action_penalty_scale;
+  HandRewardOut o;
+  o.goal_resets = ard <= p.success_tolerance ? 1 : reset_goal_in;
+  o.successes = successes + (float)o.goal_resets;
+  reward = o.goal_resets == 1 ? reward + p.reach_goal_bonus : reward;
+  const bool fell = goal_dist >= p.fall_dist;
+  reward = fell ? reward + p.fall_penalty : reward;
+  int64_t resets = fell ? 1 : reset_in;
+  if (p.max_consecutive_successes > 0) {
+    progress = ard <= p.success_tolerance ? 0 : progress;
+    resets = o.successes >= (float)p.max_consecutive_successes ? 1 : resets;
+  }
+  const bool timeout = (float)progress >= a.max_len_minus_1;
+  resets = timeout ? 1 : resets;
+  if (p.max_consecutive_successes > 0) reward = timeout ? reward + a.half_fall_penalty : reward;
+  o.reward = reward;
+  o.resets = resets;
+  o.progress = progress;
+  return o;
+}
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+  return v;
+}
+
+// OBS: 0 openai, 2 full.  ASYM: also states_buf.
+template <int OBS, bool ASYM, bool FULLTILE>
+__device__ __forceinline__ void hand_post_tile(const HandPost& a, float* __restrict__ lds, int64_t t, int nv) {
+  constexpr int OW = OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157;
+  constexpr bool NEED_FULLCOLS = ASYM || OBS == OIGE_HAND_OBS_FULL;  // dof/ft_rot/ft_vel columns wanted
+  // LDS carve: [obs tile | states tile | env_pos 64x3 | lo 24 | hi 24]
+  float* obs_t = lds;
+  float* st_t = lds + TILE * OW;
+  float* s_env = st_t + (ASYM ? TILE * HS : 0);
+  float* s_lo = s_env + TILE * 3;
+  float* s_hi = s_lo + HD;
+
+  const oige_hand_params& p = a.p;
+  const int tid = threadIdx.x;
+  const int64_t env0 = t * TILE;
+  const bool do_progress = a.stages & OIGE_STAGE_PROGRESS;
+  const bool do_metrics = a.stages & OIGE_STAGE_METRICS;
+
+  // ---- A: loads in flight
+  WgChunk<HD, HNT> c_dpos, c_dvel;
+  WgChunk<3 * HF, HNT> c_ftp;
+  WgChunk<4 * HF, HNT> c_ftr;
+  WgChunk<6 * HF, HNT> c_ftv, c_sens;
+  WgChunk<HA, HNT> c_act;
+  if (a.stages & OIGE_STAGE_OBS) {
+    wg_load_chunk<3 * HF, HNT, FULLTILE>(c_ftp, a.s.fingertip_pos + env0 * 3 * HF, nv * 3 * HF);
+    wg_load_chunk<HA, HNT, FULLTILE>(c_act, a.b.actions + env0 * HA, nv * HA);
+    if (NEED_FULLCOLS) {
+      wg_load_chunk<HD, HNT, FULLTILE>(c_dpos, a.s.hand_dof_pos + env0 * HD, nv * HD);
+      wg_load_chunk<HD, HNT, FULLTILE>(c_dvel, a.s.hand_dof_vel + env0 * HD, nv * HD);
+      wg_load_chunk<4 * HF, HNT, FULLTILE>(c_ftr, a.s.fingertip_rot + env0 * 4 * HF, nv * 4 * HF);
+      wg_load_chunk<6 * HF, HNT, FULLTILE>(c_ftv, a.s.fingertip_velocities + env0 * 6 * HF, nv * 6 * HF);
+    }
+    if (ASYM) wg_load_chunk<6 * HF, HNT, FULLTILE>(c_sens, a.s.vec_sensor + env0 * 6 * HF, nv * 6 * HF);
+  }
+
+  // per-env rows (wave 0: one env per lane)
+  const bool envlane = tid < TILE;
+  const bool live = envlane && (FULLTILE || tid < nv);
+  const int64_t env = env0 + tid;
+  f3 epos{0, 0, 0}, opos{0, 0, 0}, olin{0, 0, 0}, oang{0, 0, 0}, gpos{0, 0, 0};
+  q4 orot{1, 0, 0, 0}, grot{1, 0, 0, 0};
+  int64_t reset_in = 0, reset_goal_in = 0, progress = 0;
+  float successes = 0.f;
+  if (live) {
+    const float* e3 = a.s.env_pos + env * 3;
+    epos = f3{e3[0], e3[1], e3[2]};
+    const float* o3 = a.s.object_pos + env * 3;
+    opos = f3{o3[0], o3[1], o3[2]};
+    const float4 r4 = *reinterpret_cast<const float4*>(a.s.object_rot + env * 4);
+    orot = q4{r4.x, r4.y, r4.z, r4.w};
+    if (a.stages & OIGE_STAGE_OBS) {
+      const float2* vp = reinterpret_cast<const float2*>(a.s.object_velocities + env * 6);
+      const float2 v0 = vp[0], v1 = vp[1], v2 = vp[2];
+      olin = f3{v0.x, v0.y, v1.x};
+      oang = f3{v1.y, v2.x, v2.y};
+    }
+    const float* g3 = a.b.goal_pos + env * 3;
+    gpos = f3{g3[0], g3[1], g3[2]};
+    const float4 g4 = *reinterpret_cast<const float4*>(a.b.goal_rot + env * 4);
+    grot = q4{g4.x, g4.y, g4.z, g4.w};
+    if (do_progress || do_metrics) progress = a.b.progress_buf[env];
+    if (do_metrics) {
+      reset_in = a.b.reset_buf[env];
+      reset_goal_in = a.b.reset_goal_buf[env];
+      successes = a.b.successes[env];
+    }
+  }
+  if (envlane) {
+    s_env[tid * 3 + 0] = epos.x;
+    s_env[tid * 3 + 1] = epos.y;
+    s_env[tid * 3 + 2] = epos.z;
+  }
+  if (tid >= TILE && tid < TILE + HD) {
+    s_lo[tid - TILE] = p.dof_lower[tid - TILE];
+    s_hi[tid - TILE] = p.dof_upper[tid - TILE];
+  }
+  __syncthreads();
+
+  // ---- B: pass-through columns
+  if (a.stages & OIGE_STAGE_OBS) {
+    wg_for_each<3 * HF, HNT>(c_ftp, [&](int e, int c, float v) {
+      const float w = v - s_env[e * 3 + (c % 3)];  // fingertip_pos -= env_pos (shadow_hand.py:124-126)
+      if (OBS == OIGE_HAND_OBS_OPENAI) obs_t[e * OW + c] = w;
+      if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + 72 + c] = w;
+      if (ASYM) st_t[e * HS + 72 + c] = w;
+    });
+    wg_for_each<HA, HNT>(c_act, [&](int e, int c, float v) {
+      if (OBS == OIGE_HAND_OBS_OPENAI) obs_t[e * OW + 22 + c] = v;
+      if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + 137 + c] = v;
+      if (ASYM) st_t[e * HS + 167 + c] = v;
+    });
+    if (NEED_FULLCOLS) {
+      wg_for_each<HD, HNT>(c_dpos, [&](int e, int c, float v) {
+        const float w = unscale(v, s_lo[c], s_hi[c]);
+        if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + c] = w;
+        if (ASYM) st_t[e * HS + c] = w;
+      });
+      wg_for_each<HD, HNT>(c_dvel, [&](int e, int c, float v) {
+        const float w = p.vel_obs_scale * v;
+        if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + HD + c] = w;
+        if (ASYM) st_t[e * HS + HD + c] = w;
+      });
+      wg_for_each<4 * HF, HNT>(c_ftr, [&](int e, int c, float v) {
+        if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + 87 + c] = v;
+        if (ASYM) st_t[e * HS + 87 + c] = v;
+      });
+      wg_for_each<6 * HF, HNT>(c_ftv, [&](int e, int c, float v) {
+        if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + 107 + c] = v;
+        if (ASYM) st_t[e * HS + 107 + c] = v;
+      });
+    }
+    if (ASYM)
+      wg_for_each<6 * HF, HNT>(c_sens, [&](int e, int c, float v) { st_t[e * HS + 137 + c] = p.force_torque_obs_scale * v; });
+  }
+
+  // ---- C: per-env math (wave 0)
+  float action_penalty = 0.f;
+  if (envlane) {
+    const f3 opl{opos.x - epos.x, opos.y - epos.y, opos.z - epos.z};  // object_pos -= env_pos (:258)
+    if (a.stages & OIGE_STAGE_OBS) {
+      const q4 rel = quat_mul(orot, quat_conjugate(grot));
+      if (OBS == OIGE_HAND_OBS_OPENAI) {
+        float* r = obs_t + tid * OW;
+        r[15] = opl.x; r[16] = opl.y; r[17] = opl.z;
+        r[18] = rel.w; r[19] = rel.x; r[20] = rel.y; r[21] = rel.z;
+      }
+      if (NEED_FULLCOLS) {
+        const float blk[24] = {opl.x, opl.y, opl.z, orot.w, orot.x, orot.y, orot.z, olin.x, olin.y, olin.z,
+                               p.vel_obs_scale * oang.x, p.vel_obs_scale * oang.y, p.vel_obs_scale * oang.z,
+                               gpos.x, gpos.y, gpos.z, grot.w, grot.x, grot.y, grot.z, rel.w, rel.x, rel.y, rel.z};
+        if (OBS == OIGE_HAND_OBS_FULL) {
+#pragma unroll
+          for (int k = 0; k < 24; ++k) obs_t[tid * OW + 48 + k] = blk[k];
+        }
+        if (ASYM) {
+#pragma unroll
+          for (int k = 0; k < 24; ++k) st_t[tid * HS + 48 + k] = blk[k];
+        }
+      }
+    }
+    if (do_progress) progress += 1;  // rl_task.py:289
+    if (do_metrics) {
+      // torch.sum(actions**2, dim=-1) (:493); the tile row is read straight from global here because
+      // with OBS skipped the tile holds no actions
+      const float4* ar = reinterpret_cast<const float4*>(a.b.actions + env * HA);
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < HA / 4; ++k) {
+          const float4 v = ar[k];
+          const float s0 = v.x * v.x, s1 = v.y * v.y, s2 = v.z * v.z, s3 = v.w * v.w;
+          action_penalty = k == 0 ? s0 : action_penalty + s0;
+          action_penalty += s1;
+          action_penalty += s2;
+          action_penalty += s3;
+        }
+      }
+      const HandRewardOut o = hand_reward(a, opl, orot, gpos, grot, action_penalty, reset_in, reset_goal_in, progress, successes);
+      if (live) {
+        a.b.rew_buf[env] = o.reward;
+        a.b.reset_buf[env] = o.resets;
+        a.b.reset_goal_buf[env] = o.goal_resets;
+        a.b.progress_buf[env] = o.progress;
+        a.b.successes[env] = o.successes;
+        if (a.b.randomization_buf) a.b.randomization_buf[env] += 1;  // :297
+      }
+      const bool r1 = live && o.resets != 0, g1 = live && o.goal_resets != 0;
+      const unsigned long long mr = __ballot(r1), mg = __ballot(g1);
+      // Sum(resets) counts VALUES (a stale reset_buf could hold values other than 0/1)
+      const float nres = wave_sum_f(live ? (float)o.resets : 0.f);
+      const float fin = wave_sum_f(live ? o.successes * (float)o.resets : 0.f);  // :523
+      if (tid == 0) {
+        a.b.reset_workspace[t] = __popcll(mr);
+        a.b.goal_workspace[t] = __popcll(mg);
+        a.b.reduce_workspace[2 * t + 0] = nres;
+        a.b.reduce_workspace[2 * t + 1] = fin;
+      }
+    } else if (do_progress && live) {
+      a.b.progress_buf[env] = progress;
+    }
+  }
+  __syncthreads();
+
+  // ---- D: tiles -> HBM
+  if (a.stages & OIGE_STAGE_OBS) {
+    wg_store_tile<OW, HNT, FULLTILE>(obs_t, a.b.obs_buf + env0 * OW, nv * OW);
+    if (ASYM) wg_store_tile<HS, HNT, FULLTILE>(st_t, a.b.states_buf + env0 * HS, nv * HS);
+  }
+}
+
+template <int OBS, bool ASYM>
+__global__ __launch_bounds__(HNT) void hand_post_kernel(const HandPost a) {
+  extern __shared__ __align__(16) float lds[];
+  const int64_t t = blockIdx.x;
+  const int64_t left = a.n - t * TILE;
+  if (left >= TILE)
+    hand_post_tile<OBS, ASYM, true>(a, lds, t, TILE);
+  else
+    hand_post_tile<OBS, ASYM, false>(a, lds, t, (int)left);
+}
+
+// consecutive_successes update (:522-529): single workgroup, tile order
+__global__ __launch_bounds__(1024) void hand_finalize_kernel(const float* __restrict__ partials, int64_t tiles,
+                                                             float* __restrict__ cons, float av, float one_minus_av) {
+  __shared__ double s_n[1024 / WAVE], s_f[1024 / WAVE];
+  double n = 0.0, f = 0.0;
+  for (int64_t i = threadIdx.x; i < tiles; i += 1024) {
+    n += (double)partials[2 * i];
+    f += (double)partials[2 * i + 1];
+  }
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) {
+    n += __shfl_xor(n, off, WAVE);
+    f += __shfl_xor(f, off, WAVE);
+  }
+  if (lane_id() == 0) {
+    s_n[threadIdx.x >> 6] = n;
+    s_f[threadIdx.x >> 6] = f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double tn = 0.0, tf = 0.0;
+    for (int i = 0; i < 1024 / WAVE; ++i) {
+      tn += s_n[i];
+      tf += s_f[i];
+    }
+    const float num_resets = (float)tn;  // int64 sum promoted to fp32 at the division
+    const float fin = (float)tf;
+    if (tn > 0.0) *cons = (av * fin) / num_resets + one_minus_av * (*cons);
+  }
+}
+
+// ---------------------------------------------------------------- pre_physics / resets
+struct HandPre {
+  oige_hand_params p;
+  oige_hand_buffers b;
+  oige_hand_reset_io r;
+  const float* actions_in;
+  float* actions_out;
+  float* targets_out;
+  int64_t n;
+  uint32_t flags;
+};
+
+// U(-1,1) from Philox: torch_rand_float(-1, 1): (1 - (-1)) * u + (-1)
+__device__ __forceinline__ float um11(uint32_t w) { return 2.0f * u01(w) + (-1.0f); }
+
+// draw `count` U(-1,1) values for env i, stream `stream` into out[]
+template <int COUNT>
+__device__ __forceinline__ void hand_draw(const oige_hand_reset_io& r, int64_t i, uint32_t stream, float (&out)[COUNT]) {
+#pragma unroll
+  for (int blk = 0; blk < (COUNT + 3) / 4; ++blk) {
+    const u4 c{(uint32_t)i, (uint32_t)blk | (stream << 16), (uint32_t)r.step, (uint32_t)(r.step >> 32)};
+    const u4 x = philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+    const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (4 * blk + q < COUNT) out[4 * blk + q] = um11(w[q]);
+  }
+}
+
+// quat_from_angle_axis(angle, unit axis e_k): normalize([cos(a/2), e_k * sin(a/2)]) with normalize(axis) = axis
+template <int AXIS>
+__device__ __forceinline__ q4 quat_from_angle_unit_axis(float angle) {
+  const float th = angle / 2.0f;
+  const float s = sinf(th), c = cosf(th);
+  // normalize(axis): axis / clamp(norm, 1e-9) = (1,0,0)/1 -> exact; xyz = axis * sin
+  q4 q{c, AXIS == 0 ? 1.0f * s : 0.0f * s, AXIS == 1 ? 1.0f * s : 0.0f * s, 0.0f * s};
+  const float n = norm4(q);
+  const float d = n < 1e-9f ? 1e-9f : n;
+  return q4{q.w / d, q.x / d, q.y / d, q.z / d};
+}
+
+// randomize_rotation (:450-453)
+__device__ __forceinline__ q4 randomize_rotation(float rand0, float rand1) {
+  return quat_mul(quat_from_angle_unit_axis<0>(rand0 * OIGE_PI_F), quat_from_angle_unit_axis<1>(rand1 * OIGE_PI_F));
+}
+
+// reset_target_pose (:377-395) for env i -> compacted row k of (pos_out, rot_out)
+__device__ __forceinline__ void hand_reset_goal(const HandPre& a, int64_t i, int64_t k, const float* u4row,
+                                                uint32_t stream, float* pos_out, float* rot_out) {
+  float u[4];
+  if (u4row) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) u[q] = u4row[k * 4 + q];
+  } else {
+    hand_draw<4>(a.r, i, stream, u);
+  }
+  const q4 nr = randomize_rotation(u[0], u[1]);
+  const float* gi = a.r.goal_init_pos + i * 3;
+  const float* ep = a.r.env_pos + i * 3;
+  const float gx = gi[0], gy = gi[1], gz = gi[2];
+  a.b.goal_pos[i * 3 + 0] = gx;
+  a.b.goal_pos[i * 3 + 1] = gy;
+  a.b.goal_pos[i * 3 + 2] = gz;
+  *reinterpret_cast<float4*>(a.b.goal_rot + i * 4) = make_float4(nr.w, nr.x, nr.y, nr.z);
+  pos_out[k * 3 + 0] = (gx + a.p.goal_displacement[0]) + ep[0];
+  pos_out[k * 3 + 1] = (gy + a.p.goal_displacement[1]) + ep[1];
+  pos_out[k * 3 + 2] = (gz + a.p.goal_displacement[2]) + ep[2];
+  *reinterpret_cast<float4*>(rot_out + k * 4) = make_float4(nr.w, nr.x, nr.y, nr.z);
+  a.b.reset_goal_buf[i] = 0;
+}
+
+// reset_idx (:397-441) for env i -> compacted row k
+__device__ __forceinline__ void hand_reset_env(const HandPre& a, int64_t i, int64_t k) {
+  const oige_hand_params& p = a.p;
+  float u[2 * HD + 5];
+  if (a.r.u_reset) {
+#pragma unroll
+    for (int q = 0; q < 2 * HD + 5; ++q) u[q] = a.r.u_reset[k * (2 * HD + 5) + q];
+  } else {
+    hand_draw<2 * HD + 5>(a.r, i, 1u, u);
+  }
+  hand_reset_goal(a, i, k, a.r.u_reset_goal, 2u, a.r.r_goal_world_pos_out, a.r.r_goal_rot_out);  // :401
+  const float* oi = a.r.object_init_pos + i * 3;
+  const float* ep = a.r.env_pos + i * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a.r.object_pos_out[k * 3 + c] = (oi[c] + p.reset_position_noise * u[c]) + ep[c];  // :404-406
+  const q4 orot = randomize_rotation(u[3], u[4]);                                                       // :408-410
+  *reinterpret_cast<float4*>(a.r.object_rot_out + k * 4) = make_float4(orot.w, orot.x, orot.y, orot.z);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) a.r.object_vel_out[k * 6 + c] = 0.0f;  // :412-413
+#pragma unroll
+  for (int j = 0; j < HD; ++j) {
+    const float delta_max = p.dof_upper[j] - p.dof_default_pos[j];
+    const float delta_min = p.dof_lower[j] - p.dof_default_pos[j];
+    const float rand_delta = delta_min + ((delta_max - delta_min) * 0.5f) * (u[5 + j] + 1.0f);  // :419
+    const float pos = p.dof_default_pos[j] + p.reset_dof_pos_noise * rand_delta;                 // :421
+    const float vel = p.dof_default_vel[j] + p.reset_dof_vel_noise * u[5 + HD + j];             // :426-429
+    a.r.dof_pos_out[k * HD + j] = pos;
+    a.r.dof_vel_out[k * HD + j] = vel;
+    a.b.prev_targets[i * HD + j] = pos;  // :431-432
+    a.b.cur_targets[i * HD + j] = pos;
+  }
+  a.b.progress_buf[i] = 0;  // :439-441
+  a.b.reset_buf[i] = 0;
+  a.b.successes[i] = 0.0f;
+  a.r.env_ids[k] = i;
+}
+
+// action application for env i (:331-358), after any reset of the same env
+__device__ __forceinline__ void hand_apply_actions(const HandPre& a, int64_t i) {
+  const oige_hand_params& p = a.p;
+  float act[HA];
+  const float4* ar = reinterpret_cast<const float4*>(a.actions_in + i * HA);
+#pragma unroll
+  for (int k = 0; k < HA / 4; ++k) {
+    const float4 v = ar[k];
+    act[4 * k] = v.x; act[4 * k + 1] = v.y; act[4 * k + 2] = v.z; act[4 * k + 3] = v.w;
+  }
+  if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
+#pragma unroll
+    for (int k = 0; k < HA; ++k) act[k] = clamp_sym(act[k], p.clip_actions);
+  }
+  if (a.actions_out) {
+    float4* ao = reinterpret_cast<float4*>(a.actions_out + i * HA);
+#pragma unroll
+    for (int k = 0; k < HA / 4; ++k) ao[k] = make_float4(act[4 * k], act[4 * k + 1], act[4 * k + 2], act[4 * k + 3]);
+  }
+  float out[HA];
+  const float one_minus = p.one_minus_act_moving_average;
+  const float speed_dt = p.dof_speed_scale_dt;
+#pragma unroll
+  for (int k = 0; k < HA; ++k) {
+    const int j = p.actuated_dof_indices[k];
+    const float lo = p.dof_lower[j], hi = p.dof_upper[j];
+    const float prev = a.b.prev_targets[i * HD + j];
+    float c;
+    if (p.use_relative_control) {
+      c = tensor_clamp(prev + speed_dt * act[k], lo, hi);  // :334-341
+    } else {
+      c = scale(act[k], lo, hi);                            // :343-347
+      c = p.act_moving_average * c + one_minus * prev;     // :348-351
+      c = tensor_clamp(c, lo, hi);                          // :352-356
+    }
+    a.b.cur_targets[i * HD + j] = c;
+    a.b.prev_targets[i * HD + j] = c;  // :358
+    out[k] = c;
+  }
+  float4* to = reinterpret_cast<float4*>(a.targets_out + i * HA);
+#pragma unroll
+  for (int k = 0; k < HA / 4; ++k) to[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+}
+
+__global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
+  __shared__ int lds_a[GROUP_TILES], lds_b[GROUP_TILES];
+  const int64_t g = blockIdx.x;
+  const int64_t env = g * GROUP + threadIdx.x;
+  const int64_t G = num_groups(a.n);
+  const int32_t* off_r = a.b.reset_workspace + G * GROUP_TILES;
+  const int32_t* off_g = a.b.goal_workspace + G * GROUP_TILES;
+  const bool live = env < a.n;
+  const bool f_env = live && a.b.reset_buf[env] != 0;
+  const bool f_goal = live && a.b.reset_goal_buf[env] != 0;
+  const int64_t kg = group_rank(f_goal, off_g, g, lds_b);
+  const int64_t kr = group_rank(f_env, off_r, g, lds_a);
+  if (f_goal) {
+    hand_reset_goal(a, env, kg, a.r.u_goal, 0u, a.r.goal_world_pos_out, a.r.goal_rot_out);  // :324-327
+    a.r.goal_ids[kg] = env;
+  }
+  if (f_env) hand_reset_env(a, env, kr);  // :328-329
+  if (live) hand_apply_actions(a, env);
+  if (g == 0 && threadIdx.x == 0) {
+    *a.r.count = (int64_t)off_r[G];
+    *a.r.goal_count = (int64_t)off_g[G];
+  }
+}
+
+__global__ __launch_bounds__(256) void hand_reset_idx_kernel(const HandPre a, int64_t max_ids) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= max_ids || k >= *a.r.count) return;
+  const int64_t i = a.r.env_ids[k];
+  if (i < 0 || i >= a.n) return;
+  hand_reset_env(a, i, k);
+}
+
+__global__ __launch_bounds__(256) void hand_reset_goal_kernel(const HandPre a, int64_t max_ids) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= max_ids || k >= *a.r.goal_count) return;
+  const int64_t i = a.r.goal_ids[k];
+  if (i < 0 || i >= a.n) return;
+  hand_reset_goal(a, i, k, a.r.u_goal, 0u, a.r.goal_world_pos_out, a.r.goal_rot_out);
+}
+
+// ---------------------------------------------------------------- host dispatch
+static int check_hand(const oige_hand_params* p, const oige_hand_buffers* b, int64_t n) {
+  OIGE_REQUIRE(p && b, "hand: null params/buffers");
+  OIGE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) / 256, "hand: num_envs %lld out of range", (long long)n);
+  OIGE_REQUIRE(p->obs_type == OIGE_HAND_OBS_OPENAI || p->obs_type == OIGE_HAND_OBS_FULL,
+               "hand: observationType must be openai (0) or full (2); full_no_vel raises a shape error in the reference "
+               "(shadow_hand.py:190) and non-asymmetric full_state is dead code there (shadow_hand.py:263-306)");
+  for (int k = 0; k < OIGE_HAND_ACTIONS; ++k)
+    OIGE_REQUIRE(p->actuated_dof_indices[k] >= 0 && p->actuated_dof_indices[k] < OIGE_HAND_DOFS &&
+                     (k == 0 || p->actuated_dof_indices[k] > p->actuated_dof_indices[k - 1]),
+                 "hand: actuated_dof_indices must be 20 ascending indices below 24");
+  return OIGE_OK;
+}
+
+template <int OBS, bool ASYM>
+static int launch_hand_post(const HandPost& a, hipStream_t s) {
+  constexpr int OW = OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157;
+  const size_t lds = sizeof(float) * (TILE * OW + (ASYM ? TILE * HS : 0) + TILE * 3 + 2 * HD);
+  static bool configured = false;
+  if (!configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hand_post_kernel<OBS, ASYM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return fail(OIGE_ELAUNCH, "hand_post_kernel: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    configured = true;
+  }
+  hipLaunchKernelGGL((hand_post_kernel<OBS, ASYM>), dim3((unsigned)num_tiles(a.n)), dim3(HNT), lds, s, a);
+  return check_launch("hand_post_kernel");
+}
+
+}  // namespace oige
+
+using namespace oige;
+
+extern "C" {
+
+int oige_hand_post_physics(const oige_hand_params* params, const oige_hand_state* state,
+                           const oige_hand_buffers* buffers, int64_t num_envs, uint32_t stages, oige_stream_t stream) {
+  if (int rc = check_hand(params, buffers, num_envs)) return rc;
+  OIGE_REQUIRE((stages & ~OIGE_STAGE_ALL) == 0 && stages != 0, "hand_post_physics: bad stages mask 0x%x", stages);
+  stages &= ~OIGE_STAGE_DONE;  // is_done is `pass` in the reference (:374-375)
+  if (stages == 0 || num_envs == 0) return OIGE_OK;
+  OIGE_REQUIRE(state != nullptr, "hand_post_physics: null state");
+  const oige_hand_buffers& b = *buffers;
+  const oige_hand_state& st = *state;
+  const bool asym = params->asymmetric_obs != 0;
+  OIGE_REQUIRE(st.object_pos && st.object_rot && st.env_pos && b.goal_pos && b.goal_rot && b.actions && b.progress_buf,
+               "hand_post_physics: null object/goal/actions/progress pointer");
+  OIGE_REQUIRE(aligned16(st.object_rot) && aligned16(b.goal_rot) && aligned16(b.actions),
+               "hand_post_physics: object_rot/goal_rot/actions must be 16-byte aligned");
+  if (stages & OIGE_STAGE_OBS) {
+    OIGE_REQUIRE(b.obs_buf && aligned16(b.obs_buf), "hand_post_physics: obs_buf null or unaligned");
+    OIGE_REQUIRE(st.object_velocities && st.fingertip_pos && aligned16(st.fingertip_pos) &&
+                     (reinterpret_cast<uintptr_t>(st.object_velocities) & 7u) == 0,
+                 "hand_post_physics: null/unaligned object_velocities or fingertip_pos");
+    if (asym || params->obs_type == OIGE_HAND_OBS_FULL)
+      OIGE_REQUIRE(st.fingertip_rot && st.fingertip_velocities && st.hand_dof_pos && st.hand_dof_vel &&
+                       aligned16(st.fingertip_rot) && aligned16(st.fingertip_velocities) && aligned16(st.hand_dof_pos) &&
+                       aligned16(st.hand_dof_vel),
+                   "hand_post_physics: null/unaligned fingertip or hand dof state");
+    if (asym)
+      OIGE_REQUIRE(b.states_buf && st.vec_sensor && aligned16(b.states_buf) && aligned16(st.vec_sensor),
+                   "hand_post_physics: asymmetric_obs needs states_buf and vec_sensor (16-byte aligned)");
+  }
+  if (stages & OIGE_STAGE_METRICS)
+    OIGE_REQUIRE(b.rew_buf && b.reset_buf && b.reset_goal_buf && b.successes && b.consecutive_successes &&
+                     b.reset_workspace && b.goal_workspace && b.reduce_workspace,
+                 "hand_post_physics: null reward/reset/successes/workspace pointer");
+  HandPost a;
+  a.p = *params;
+  a.s = st;
+  a.b = b;
+  a.n = num_envs;
+  a.stages = stages;
+  a.max_len_minus_1 = (float)((double)params->max_episode_length - 1.0);
+  a.half_fall_penalty = (float)(0.5 * (double)params->fall_penalty);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (params->obs_type == OIGE_HAND_OBS_OPENAI)
+    rc = asym ? launch_hand_post<OIGE_HAND_OBS_OPENAI, true>(a, s) : launch_hand_post<OIGE_HAND_OBS_OPENAI, false>(a, s);
+  else
+    rc = asym ? launch_hand_post<OIGE_HAND_OBS_FULL, true>(a, s) : launch_hand_post<OIGE_HAND_OBS_FULL, false>(a, s);
+  if (rc) return rc;
+  if (stages & OIGE_STAGE_METRICS) {
+    const float av = params->av_factor;  // reaches the jit function as float(fp32 tensor) (:59,:293)
+    hipLaunchKernelGGL(hand_finalize_kernel, dim3(1), dim3(1024), 0, s, b.reduce_workspace, num_tiles(num_envs),
+                       b.consecutive_successes, av, (float)(1.0 - (double)av));
+    return check_launch("hand_finalize_kernel");
+  }
+  return OIGE_OK;
+}
+
+static int fill_pre(HandPre& a, const oige_hand_params* params, const oige_hand_buffers* buffers,
+                    const oige_hand_reset_io* r, int64_t n) {
+  if (int rc = check_hand(params, buffers, n)) return rc;
+  OIGE_REQUIRE(r != nullptr, "hand: null reset_io");
+  OIGE_REQUIRE(r->object_init_pos && r->goal_init_pos && r->env_pos, "hand: null init pointer");
+  const oige_hand_buffers& b = *buffers;
+  OIGE_REQUIRE(b.goal_pos && b.goal_rot && b.reset_buf && b.reset_goal_buf && b.progress_buf && b.successes &&
+                   b.prev_targets && b.cur_targets,
+               "hand: null goal/reset/progress/successes/targets pointer");
+  OIGE_REQUIRE(aligned16(b.goal_rot), "hand: goal_rot must be 16-byte aligned");
+  a.p = *params;
+  a.b = b;
+  a.r = *r;
+  a.n = n;
+  a.flags = 0;
+  a.actions_in = nullptr;
+  a.actions_out = nullptr;
+  a.targets_out = nullptr;
+  return OIGE_OK;
+}
+
+int oige_hand_pre_physics(const oige_hand_params* params, const float* actions_in, const oige_hand_buffers* buffers,
+                          const oige_hand_reset_io* reset_io, float* actions_out, float* targets_out, int64_t num_envs,
+                          uint32_t flags, oige_stream_t stream) {
+  HandPre a;
+  if (int rc = fill_pre(a, params, buffers, reset_io, num_envs)) return rc;
+  const oige_hand_reset_io& r = *reset_io;
+  OIGE_REQUIRE(actions_in && targets_out && aligned16(actions_in) && aligned16(targets_out) && aligned16(actions_out),
+               "hand_pre_physics: null/unaligned actions or targets");
+  OIGE_REQUIRE(buffers->reset_workspace && buffers->goal_workspace && aligned16(buffers->reset_workspace) &&
+                   aligned16(buffers->goal_workspace),
+               "hand_pre_physics: null/unaligned workspaces");
+  OIGE_REQUIRE(r.goal_ids && r.goal_count && r.goal_world_pos_out && r.goal_rot_out && r.env_ids && r.count &&
+                   r.r_goal_world_pos_out && r.r_goal_rot_out && r.object_pos_out && r.object_rot_out && r.object_vel_out &&
+                   r.dof_pos_out && r.dof_vel_out,
+               "hand_pre_physics: null reset output pointer");
+  OIGE_REQUIRE(aligned16(r.goal_rot_out) && aligned16(r.r_goal_rot_out) && aligned16(r.object_rot_out),
+               "hand_pre_physics: (n,4) outputs must be 16-byte aligned");
+  OIGE_REQUIRE(!r.u_goal && !r.u_reset && !r.u_reset_goal,
+               "hand_pre_physics: pre-drawn noise goes through oige_hand_reset_idx / oige_hand_reset_target_pose");
+  a.actions_in = actions_in;
+  a.actions_out = actions_out;
+  a.targets_out = targets_out;
+  a.flags = flags;
+  const int64_t G = num_groups(num_envs);
+  if (G == 0) return OIGE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (!(flags & OIGE_PRE_COUNTS_VALID)) {
+    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
+    if (int rc = launch_count_flags(a.b.reset_goal_buf, num_envs, a.b.goal_workspace, s)) return rc;
+  }
+  if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
+  if (int rc = launch_scan_groups(num_envs, a.b.goal_workspace, s)) return rc;
+  hipLaunchKernelGGL(hand_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  return check_launch("hand_pre_kernel");
+}
+
+int oige_hand_reset_idx(const oige_hand_params* params, const oige_hand_buffers* buffers,
+                        const oige_hand_reset_io* reset_io, int64_t num_envs, int64_t max_ids, oige_stream_t stream) {
+  HandPre a;
+  if (int rc = fill_pre(a, params, buffers, reset_io, num_envs)) return rc;
+  const oige_hand_reset_io& r = *reset_io;
+  OIGE_REQUIRE(max_ids >= 0 && max_ids <= num_envs, "hand_reset_idx: bad max_ids");
+  OIGE_REQUIRE(r.env_ids && r.count && r.r_goal_world_pos_out && r.r_goal_rot_out && r.object_pos_out && r.object_rot_out &&
+                   r.object_vel_out && r.dof_pos_out && r.dof_vel_out,
+               "hand_reset_idx: null reset pointer");
+  OIGE_REQUIRE((r.u_reset == nullptr) == (r.u_reset_goal == nullptr), "hand_reset_idx: pass both u_reset and u_reset_goal or neither");
+  OIGE_REQUIRE(aligned16(r.r_goal_rot_out) && aligned16(r.object_rot_out), "hand_reset_idx: (n,4) outputs must be 16-byte aligned");
+  if (max_ids == 0) return OIGE_OK;
+  hipLaunchKernelGGL(hand_reset_idx_kernel, dim3((unsigned)((max_ids + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, max_ids);
+  return check_launch("hand_reset_idx_kernel");
+}
+
+int oige_hand_reset_target_pose(const oige_hand_params* params, const oige_hand_buffers* buffers,
+                                const oige_hand_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                                oige_stream_t stream) {
+  HandPre a;
+  if (int rc = fill_pre(a, params, buffers, reset_io, num_envs)) return rc;
+  const oige_hand_reset_io& r = *reset_io;
+  OIGE_REQUIRE(max_ids >= 0 && max_ids <= num_envs, "hand_reset_target_pose: bad max_ids");
+  OIGE_REQUIRE(r.goal_ids && r.goal_count && r.goal_world_pos_out && r.goal_rot_out && aligned16(r.goal_rot_out),
+               "hand_reset_target_pose: null/unaligned goal pointer");
+  if (max_ids == 0) return OIGE_OK;
+  hipLaunchKernelGGL(hand_reset_goal_kernel, dim3((unsigned)((max_ids + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, max_ids);
+  return check_launch("hand_reset_goal_kernel");
+}
+
+}  // extern "C"

@@ -98,3 +98,77 @@ __device__ __forceinline__ void store_tile(const float* __restrict__ tile, float
 }
 
 }  // namespace oige
+
+// ------------------------------------------------------------------------------------------
+// Workgroup-cooperative variants: NT threads (NT/64 waves) share ONE 64-env tile.  Used by the
+// wide-row tasks (ShadowHand 187-float state rows, AnymalTerrain 188-float obs rows) where a
+// tile is ~48 KB of LDS: four waves per tile keep 8-12 waves per CU resident instead of 2-3.
+namespace oige {
+
+template <int K, int NT>
+struct WgChunk {
+  static constexpr int NF4 = (TILE * K) / 4;
+  static constexpr int ITERS = (NF4 + NT - 1) / NT;
+  float4 v[ITERS];
+};
+
+template <int K, int NT, bool FULL>
+__device__ __forceinline__ void wg_load_chunk(WgChunk<K, NT>& c, const float* __restrict__ src, int valid) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < WgChunk<K, NT>::ITERS; ++it) {
+    const int f = it * NT + tid;
+    const int e = 4 * f;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f < WgChunk<K, NT>::NF4) {
+      if (FULL || e + 3 < valid) {
+        t = *reinterpret_cast<const float4*>(src + e);
+      } else {
+        if (e + 0 < valid) t.x = src[e + 0];
+        if (e + 1 < valid) t.y = src[e + 1];
+        if (e + 2 < valid) t.z = src[e + 2];
+      }
+    }
+    c.v[it] = t;
+  }
+}
+
+// fn(env_in_tile, column, value) for every element of the run this thread holds
+template <int K, int NT, typename F>
+__device__ __forceinline__ void wg_for_each(const WgChunk<K, NT>& c, F&& fn) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < WgChunk<K, NT>::ITERS; ++it) {
+    const int f = it * NT + tid;
+    if (f >= WgChunk<K, NT>::NF4) continue;
+    const int e = 4 * f;
+    const float tv[4] = {c.v[it].x, c.v[it].y, c.v[it].z, c.v[it].w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ee = e + k;
+      fn(ee / K, ee % K, tv[k]);
+    }
+  }
+}
+
+template <int ROW, int NT, bool FULL>
+__device__ __forceinline__ void wg_store_tile(const float* __restrict__ tile, float* __restrict__ dst, int valid) {
+  constexpr int NF4 = (TILE * ROW) / 4;
+  constexpr int ITERS = (NF4 + NT - 1) / NT;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int it = 0; it < ITERS; ++it) {
+    const int f = it * NT + tid;
+    const int e = 4 * f;
+    if (f >= NF4) continue;
+    if (FULL || e + 3 < valid) {
+      *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(tile + e);
+    } else {
+      if (e + 0 < valid) dst[e + 0] = tile[e + 0];
+      if (e + 1 < valid) dst[e + 1] = tile[e + 1];
+      if (e + 2 < valid) dst[e + 2] = tile[e + 2];
+    }
+  }
+}
+
+}  // namespace oige

@@ -139,11 +139,51 @@ class SyntheticArticulationView:
         else:
             self._scatter(self.joint_efforts, efforts, indices, count)
 
-    def set_joint_position_targets(self, positions: Tensor, indices=None, count=None) -> None:
-        if indices is None or (count is None and indices.shape[0] == self.count):
+    def set_joint_position_targets(self, positions: Tensor, indices=None, joint_indices=None, count=None) -> None:
+        if joint_indices is not None:
+            # all envs, a subset of joints (in_hand_manipulation.py:360-362): keep the (N, len(joint_indices)) block
+            self.joint_position_targets_subset = (positions, joint_indices)
+        elif indices is None or (count is None and indices.shape[0] == self.count):
             self.joint_position_targets = positions
         else:
             self._scatter(self.joint_position_targets, positions, indices, count)
+
+    def set_world_poses(self, positions: Optional[Tensor] = None, orientations: Optional[Tensor] = None, indices=None,
+                        count=None) -> None:
+        if positions is not None:
+            self._scatter(self.positions, positions, indices, count)
+        if orientations is not None:
+            self._scatter(self.orientations, orientations, indices, count)
+
+    def set_velocities(self, velocities: Tensor, indices=None, count=None) -> None:
+        self._scatter(self.velocities, velocities, indices, count)
+
+
+class SyntheticRigidPrimView:
+    """RigidPrimView slice the hand task uses (in_hand_manipulation.py:257-259,394,413-414;
+    shadow_hand.py:123,127): world poses and velocities of ``count`` rigid bodies."""
+
+    def __init__(self, name: str, count: int, device, apply_resets: bool = True) -> None:
+        self.name = name
+        self.count = count
+        self._device = torch.device(device)
+        self.apply_resets = apply_resets
+        f = dict(dtype=torch.float32, device=self._device)
+        self.positions = torch.zeros((count, 3), **f)
+        self.orientations = torch.zeros((count, 4), **f)
+        self.orientations[:, 0] = 1.0
+        self.velocities = torch.zeros((count, 6), **f)
+
+    def get_world_poses(self, clone: bool = True):
+        if clone:
+            return self.positions.clone(), self.orientations.clone()
+        return self.positions, self.orientations
+
+    def get_velocities(self, clone: bool = True) -> Tensor:
+        return self.velocities.clone() if clone else self.velocities
+
+    _rows = SyntheticArticulationView._rows
+    _scatter = SyntheticArticulationView._scatter
 
     def set_world_poses(self, positions: Optional[Tensor] = None, orientations: Optional[Tensor] = None, indices=None,
                         count=None) -> None:

@@ -70,6 +70,48 @@ TASK_DEFAULTS: Dict[str, Dict[str, Any]] = {
     },
 }
 
+# cfg/task/ShadowHand.yaml:7-49, :139-158 (domain_randomization: obs/action noise part only)
+_SHADOW_HAND_ENV = {
+    "numEnvs": 8192, "envSpacing": 0.75, "episodeLength": 600,
+    "clipObservations": 5.0, "clipActions": 1.0,
+    "useRelativeControl": False, "dofSpeedScale": 20.0, "actionsMovingAverage": 1.0, "controlFrequencyInv": 2,
+    "startPositionNoise": 0.01, "startRotationNoise": 0.0,
+    "resetPositionNoise": 0.01, "resetRotationNoise": 0.0,
+    "resetDofPosRandomInterval": 0.2, "resetDofVelRandomInterval": 0.0,
+    "forceScale": 0.0, "forceProbRange": [0.001, 0.1], "forceDecay": 0.99, "forceDecayInterval": 0.08,
+    "distRewardScale": -10.0, "rotRewardScale": 1.0, "rotEps": 0.1, "actionPenaltyScale": -0.0002,
+    "reachGoalBonus": 250, "fallDistance": 0.24, "fallPenalty": 0.0, "velObsScale": 0.2,
+    "objectType": "block", "observationType": "full", "asymmetric_observations": False,
+    "successTolerance": 0.1, "printNumSuccesses": False, "maxConsecutiveSuccesses": 0,
+}
+_SHADOW_HAND_DR = {
+    "randomize": False,
+    "min_frequency": 720,
+    "randomization_params": {
+        "observations": {
+            "on_reset": {"operation": "additive", "distribution": "gaussian", "distribution_parameters": [0, 0.0001]},
+            "on_interval": {"frequency_interval": 1, "operation": "additive", "distribution": "gaussian",
+                            "distribution_parameters": [0, 0.002]},
+        },
+        "actions": {
+            "on_reset": {"operation": "additive", "distribution": "gaussian", "distribution_parameters": [0, 0.015]},
+            "on_interval": {"frequency_interval": 1, "operation": "additive", "distribution": "gaussian",
+                            "distribution_parameters": [0.0, 0.05]},
+        },
+    },
+}
+TASK_DEFAULTS["ShadowHand"] = {"name": "ShadowHand", "env": dict(_SHADOW_HAND_ENV), "sim": dict(_SIM),
+                              "domain_randomization": copy.deepcopy(_SHADOW_HAND_DR)}
+# cfg/task/ShadowHandOpenAI_FF.yaml:7-51 (resetTime 8 s, 20 Hz control, asymmetric states, mcs 50)
+_OPENAI_FF_ENV = dict(_SHADOW_HAND_ENV)
+_OPENAI_FF_ENV.update({
+    "episodeLength": 160, "resetTime": 8, "actionsMovingAverage": 0.3, "controlFrequencyInv": 3, "forceScale": 1.0,
+    "fallPenalty": -50.0, "observationType": "openai", "asymmetric_observations": True, "successTolerance": 0.4,
+    "maxConsecutiveSuccesses": 50, "averFactor": 0.1,
+})
+TASK_DEFAULTS["ShadowHandOpenAI_FF"] = {"name": "ShadowHand", "env": _OPENAI_FF_ENV, "sim": dict(_SIM),
+                                       "domain_randomization": copy.deepcopy(_SHADOW_HAND_DR)}
+
 
 def task_config(name: str, num_envs: Optional[int] = None, **env_overrides: Any) -> Dict[str, Any]:
     cfg = copy.deepcopy(TASK_DEFAULTS[name])

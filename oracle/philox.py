@@ -40,14 +40,14 @@ def u01(x: np.ndarray) -> np.ndarray:
     return (x >> np.uint32(8)).astype(np.float32) * np.float32(2.0**-24)
 
 
-def uniforms(env_ids: np.ndarray, num_draws: int, seed: int, step: int) -> np.ndarray:
+def uniforms(env_ids: np.ndarray, num_draws: int, seed: int, step: int, stream: int = 0) -> np.ndarray:
     """(len(env_ids), num_draws) fp32 uniforms: draw j of env i = word (j % 4) of the Philox block
-    with counter (i, j // 4, step_lo, step_hi) and key (seed_lo, seed_hi)."""
+    with counter (i, (j // 4) | stream << 16, step_lo, step_hi) and key (seed_lo, seed_hi)."""
     env_ids = np.asarray(env_ids, dtype=np.uint64)
     nblk = (num_draws + 3) // 4
     out = np.zeros((env_ids.shape[0], nblk * 4), dtype=np.float32)
     for blk in range(nblk):
-        w = philox4x32_10(env_ids & MASK, np.uint64(blk), np.uint64(step & 0xFFFFFFFF), np.uint64((step >> 32) & 0xFFFFFFFF),
+        w = philox4x32_10(env_ids & MASK, np.uint64(blk | (stream << 16)), np.uint64(step & 0xFFFFFFFF), np.uint64((step >> 32) & 0xFFFFFFFF),
                           seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
         for q in range(4):
             out[:, 4 * blk + q] = u01(w[q])

@@ -1,0 +1,233 @@
+"""-m gpu parity tests: HIP ShadowHand path (through the C ABI) vs the CPU oracle.
+Bar: reset / goal-reset flags, reset ids, progress bit-exact; fp32 obs, states, rewards,
+successes, consecutive_successes within 1e-5 rel / 1e-6 abs (north_star)."""
+import pytest
+import torch
+
+from helpers import assert_close, assert_equal, make_task
+from omniisaacgymenvs_amd.sim import workloads
+from oracle import hand_oracle as ho
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "ShadowHand": dict(),                                   # obs=full 157, no states, mcs=0
+    "ShadowHandOpenAI_FF": dict(),                          # obs=openai 42 + asymmetric states 187, mcs=50
+    "ShadowHand/full+asym": dict(asymmetric_observations=True, maxConsecutiveSuccesses=5, fallPenalty=-50.0),
+    "ShadowHandOpenAI_FF/no-asym": dict(asymmetric_observations=False),
+}
+
+
+def _task(cfg_name, n, **over):
+    base = cfg_name.split("/")[0]
+    kw = dict(CONFIGS[cfg_name])
+    kw.update(over)
+    return make_task(base, n, **kw)
+
+
+def _spec(task) -> ho.HandSpec:
+    return ho.HandSpec(
+        obs_type=task.obs_type, asymmetric_obs=bool(task.asymmetric_obs), dist_reward_scale=task.dist_reward_scale,
+        rot_reward_scale=task.rot_reward_scale, rot_eps=task.rot_eps, action_penalty_scale=task.action_penalty_scale,
+        success_tolerance=task.success_tolerance, reach_goal_bonus=task.reach_goal_bonus, fall_dist=task.fall_dist,
+        fall_penalty=task.fall_penalty, vel_obs_scale=task.vel_obs_scale, reset_position_noise=task.reset_position_noise,
+        reset_dof_pos_noise=task.reset_dof_pos_noise, reset_dof_vel_noise=task.reset_dof_vel_noise,
+        hand_dof_speed_scale=task.hand_dof_speed_scale, use_relative_control=task.use_relative_control,
+        act_moving_average=task.act_moving_average, max_episode_length=task.max_episode_length,
+        max_consecutive_successes=task.max_consecutive_successes, av_factor=float(task.av_factor),
+        actuated_dof_indices=list(task.actuated_dof_indices), lower=task.hand_dof_lower_limits.cpu(),
+        upper=task.hand_dof_upper_limits.cpu())
+
+
+def _loaded(cfg_name, n, seed=1234, **over):
+    env, task = _task(cfg_name, n, **over)
+    st = workloads.hand_state(n, task._env_pos.cpu(), task.goal_pos.cpu(), task.hand_dof_lower_limits.cpu(),
+                              task.hand_dof_upper_limits.cpu(), device="cpu", seed=seed)
+    if n >= 8:  # progress straddling the episode length, successes straddling mcs
+        m = task.max_episode_length
+        st["progress"][:4] = torch.tensor([m - 3, m - 2, m - 1, m])
+        st["successes"][4:8] = torch.tensor([48.0, 49.0, 50.0, 3.0])
+    workloads.load_hand_state(task, st)
+    task.consecutive_successes.fill_(2.5)
+    task.prev_targets.copy_(torch.rand(n, 24, generator=torch.Generator().manual_seed(seed)).to(task.device))
+    task.cur_targets.copy_(task.prev_targets)
+    return env, task, st
+
+
+def _oracle_state(task, st) -> ho.HandState:
+    return ho.HandState(st["object_pos"], st["object_rot"], st["object_vel"], st["ft_pos"], st["ft_rot"], st["ft_vel"],
+                        st["dof_pos"], st["dof_vel"], st["sensors"], task._env_pos.cpu())
+
+
+def _oracle_buffers(task) -> ho.HandBuffers:
+    c = lambda t: t.detach().cpu().clone()
+    return ho.HandBuffers(c(task.obs_buf), c(task.states_buf), c(task.rew_buf), c(task.reset_buf), c(task.reset_goal_buf),
+                          c(task.progress_buf), c(task.successes), c(task.consecutive_successes), c(task.goal_pos),
+                          c(task.goal_rot), c(task.actions), c(task.prev_targets), c(task.cur_targets))
+
+
+def _threshold_mask(spec, s, b):
+    """Envs whose oracle rot_dist / goal_dist sit within 1e-6 of a decision threshold may land on
+    the other side in fp32 (SURVEY.md appendix A.3 flip-risk compares); they are excluded."""
+    from oracle import torch_utils as tu
+    gd = torch.norm((s.object_pos - s.env_pos) - b.goal_pos, p=2, dim=-1)
+    qd = tu.quat_mul(s.object_rot, tu.quat_conjugate(b.goal_rot))
+    rd = 2.0 * torch.asin(torch.clamp(torch.norm(qd[:, 1:4], p=2, dim=-1), max=1.0))
+    return ((rd.abs() - spec.success_tolerance).abs() > 1e-6) & ((gd - spec.fall_dist).abs() > 1e-6)
+
+
+@pytest.mark.parametrize("cfg_name", list(CONFIGS))
+@pytest.mark.parametrize("n", [1, 64, 257, 4096])
+@pytest.mark.parametrize("fused", [True, False])
+def test_post_physics_matches_oracle(cfg_name, n, fused):
+    env, task, st = _loaded(cfg_name, n)
+    task.fused = fused
+    spec, s, b = _spec(task), _oracle_state(task, st), _oracle_buffers(task)
+    ok = _threshold_mask(spec, s, b)
+    ho.post_physics(spec, s, b)
+    obs, rew, reset, extras = task.post_physics_step()
+    torch.cuda.synchronize()
+    assert bool(ok.all()) or n > 1000
+    assert_equal(reset[ok], b.reset_buf[ok], "reset_buf")
+    assert_equal(task.reset_goal_buf[ok], b.reset_goal_buf[ok], "reset_goal_buf")
+    assert_equal(task.progress_buf[ok], b.progress_buf[ok], "progress_buf")
+    assert_close(obs, b.obs_buf, "obs_buf")
+    if spec.asymmetric_obs:
+        assert_close(task.states_buf, b.states_buf, "states_buf")
+    assert_close(rew[ok], b.rew_buf[ok], "rew_buf")
+    assert_close(task.successes[ok], b.successes[ok], "successes")
+    if bool(ok.all()):
+        assert_close(task.consecutive_successes, b.consecutive_successes, "consecutive_successes")
+        assert_close(extras["consecutive_successes"].reshape(1), b.consecutive_successes.mean().reshape(1), "extras")
+    tiles = (n + 63) // 64
+    pad = lambda t: torch.nn.functional.pad(t, (0, tiles * 64 - n)).view(tiles, 64).ne(0).sum(-1).int()
+    assert_equal(task._reset_workspace[:tiles], pad(task.reset_buf.cpu()), "reset tile counts")
+    assert_equal(task._goal_workspace[:tiles], pad(task.reset_goal_buf.cpu()), "goal tile counts")
+
+
+def test_no_resets_leaves_consecutive_successes_unchanged():
+    env, task, st = _loaded("ShadowHand", 300)
+    # far from the goal rotation, near the goal position, progress small: nothing resets
+    st["object_pos"] = (task.goal_pos.cpu() + task._env_pos.cpu()).contiguous()
+    st["progress"][:] = 5
+    st["reset"][:] = 0
+    st["object_rot"] = torch.tensor([0.0, 1.0, 0.0, 0.0]).repeat(300, 1)
+    st["goal_rot"] = torch.tensor([1.0, 0.0, 0.0, 0.0]).repeat(300, 1)
+    workloads.load_hand_state(task, st)
+    task.post_physics_step()
+    torch.cuda.synchronize()
+    assert int(task.reset_buf.sum().item()) == 0
+    assert task.consecutive_successes.item() == 2.5
+
+
+@pytest.mark.parametrize("cfg_name", ["ShadowHand", "ShadowHandOpenAI_FF"])
+@pytest.mark.parametrize("n,relative", [(64, False), (1000, False), (1000, True)])
+def test_sync_free_pre_physics_matches_oracle(cfg_name, n, relative):
+    env, task, st = _loaded(cfg_name, n, useRelativeControl=relative)
+    st["reset"] = (torch.rand(n, generator=torch.Generator().manual_seed(3)) < 0.2).long()
+    st["reset_goal"] = (torch.rand(n, generator=torch.Generator().manual_seed(4)) < 0.3).long()
+    workloads.load_hand_state(task, st)
+    spec, b = _spec(task), _oracle_buffers(task)
+    init = ho.HandInit(task.object_init_pos.cpu(), task.goal_init_pos.cpu(), task._env_pos.cpu(),
+                       task.hand_dof_default_pos.cpu(), task.hand_dof_default_vel.cpu())
+    seed, step = task._rand_seed, task._step_count + 1
+    um = lambda ids, k, stream: torch.from_numpy(2.0 * philox.uniforms(ids.numpy(), k, seed, step, stream) + (-1.0)).float()
+    actions = torch.rand(n, 20, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    targets, gids, grows, eids, rrows = ho.pre_physics(
+        spec, b, init, actions, draw_goal=lambda ids: um(ids, 4, 0), draw_reset=lambda ids: (um(ids, 53, 1), um(ids, 4, 2)))
+    for v in (task._hands, task._objects, task._goals):
+        v.apply_resets = False
+    task.pre_physics_step(actions.to(task.device))
+    torch.cuda.synchronize()
+    o = task._reset_out
+    kg, ke = int(o["goal_count"].item()), int(o["count"].item())
+    assert kg == len(gids) and ke == len(eids)
+    assert_equal(o["goal_ids"][:kg], gids, "goal ids")
+    assert_equal(o["env_ids"][:ke], eids, "env ids")
+    for name in ("reset_buf", "reset_goal_buf", "progress_buf"):
+        assert_equal(getattr(task, name), getattr(b, name), name)
+    assert_equal(task.successes, b.successes, "successes")
+    assert_equal(task.actions, b.actions, "actions clone")
+    assert_close(task.goal_pos, b.goal_pos, "goal_pos")
+    assert_close(task.goal_rot, b.goal_rot, "goal_rot")
+    assert_close(task.cur_targets, b.cur_targets, "cur_targets")
+    assert_close(task.prev_targets, b.prev_targets, "prev_targets")
+    assert_close(task._targets_out, targets, "targets passed to set_joint_position_targets")
+    if grows is not None:
+        assert_close(o["goal_world_pos"][:kg], grows[0], "goal world pos rows")
+        assert_close(o["goal_rot"][:kg], grows[1], "goal rot rows")
+    if rrows is not None:
+        assert_close(o["r_goal_world_pos"][:ke], rrows["goal_world_pos"], "reset goal world pos")
+        assert_close(o["r_goal_rot"][:ke], rrows["goal_rot"], "reset goal rot")
+        assert_close(o["object_pos"][:ke], rrows["object_pos"], "object pos rows")
+        assert_close(o["object_rot"][:ke], rrows["object_rot"], "object rot rows")
+        assert_equal(o["object_vel"][:ke], rrows["object_vel"], "object vel rows")
+        assert_close(o["dof_pos"][:ke], rrows["dof_pos"], "dof pos rows")
+        assert_close(o["dof_vel"][:ke], rrows["dof_vel"], "dof vel rows")
+
+
+def test_reset_idx_and_target_pose_use_torch_draws_like_the_reference():
+    n = 500
+    env, task, st = _loaded("ShadowHandOpenAI_FF", n)
+    spec, b = _spec(task), _oracle_buffers(task)
+    init = ho.HandInit(task.object_init_pos.cpu(), task.goal_init_pos.cpu(), task._env_pos.cpu(),
+                       task.hand_dof_default_pos.cpu(), task.hand_dof_default_vel.cpu())
+    ids = torch.tensor([0, 1, 63, 64, 255, 256, 499])
+    gids = torch.tensor([2, 64, 300])
+    torch.manual_seed(31)
+    task.reset_target_pose(gids.to(task.device))
+    task.reset_idx(ids.to(task.device))
+    torch.cuda.synchronize()
+    torch.manual_seed(31)
+    ug = (2.0 * torch.rand(len(gids), 4, device=task.device) + (-1.0)).cpu()
+    ur = (2.0 * torch.rand(len(ids), 53, device=task.device) + (-1.0)).cpu()
+    urg = (2.0 * torch.rand(len(ids), 4, device=task.device) + (-1.0)).cpu()
+    ho.reset_target_pose(spec, b, init, gids, ug)
+    rows = ho.reset_idx(spec, b, init, ids, ur, urg)
+    assert_close(task.goal_rot, b.goal_rot, "goal_rot")
+    assert_close(task.goal_pos, b.goal_pos, "goal_pos")
+    assert_close(task._hands.joint_positions[ids.to(task.device)], rows["dof_pos"], "hand dof pos")
+    assert_close(task._objects.positions[ids.to(task.device)], rows["object_pos"], "object pos")
+    assert_close(task._objects.orientations[ids.to(task.device)], rows["object_rot"], "object rot")
+    assert_close(task._goals.positions[ids.to(task.device)], rows["goal_world_pos"], "goal world pos")
+    for name in ("reset_buf", "reset_goal_buf", "progress_buf"):
+        assert_equal(getattr(task, name), getattr(b, name), name)
+    assert_close(task.prev_targets, b.prev_targets, "prev_targets")
+
+
+def test_unsupported_observation_types_fail_like_the_reference():
+    env, task = make_task("ShadowHand", 64, observationType="openai")
+    task.obs_type = "full_no_vel"
+    with pytest.raises(Exception, match="full_no_vel"):
+        task.post_physics_step()
+
+
+def test_full_size_properties():
+    """C4 size (1M envs, openai obs + asymmetric states): pass-through columns equal their inputs,
+    reset ids == nonzero(), consecutive_successes equals the closed form on the outputs."""
+    n = 1 << 20
+    env, task, st = _loaded("ShadowHandOpenAI_FF", n)
+    cons0 = task.consecutive_successes.item()
+    task.post_physics_step()
+    torch.cuda.synchronize()
+    states = task.states_buf
+    assert_equal(states[:, 167:187], st["actions"], "states actions")
+    assert_equal(states[:, 87:107], st["ft_rot"].view(n, 20), "states fingertip rot")
+    assert_equal(states[:, 137:167], 10.0 * st["sensors"].view(n, 30), "states sensors")
+    assert_equal(task.obs_buf[:, 22:42], st["actions"], "obs actions")
+    assert_equal(task.obs_buf[:, 0:15], states[:, 72:87].cpu(), "openai fingertip pos == states fingertip pos")
+    resets, succ = task.reset_buf.double(), task.successes.double()
+    num = resets.sum().item()
+    want = 0.1 * (succ * resets).sum().item() / num + 0.9 * cons0
+    assert abs(task.consecutive_successes.item() - want) <= 1e-5 * abs(want) + 1e-6
+    want_ids, want_gids = task.reset_buf.nonzero().squeeze(-1).clone(), task.reset_goal_buf.nonzero().squeeze(-1).clone()
+    for v in (task._hands, task._objects, task._goals):
+        v.apply_resets = False
+    task.pre_physics_step(st["actions"].to(task.device))
+    torch.cuda.synchronize()
+    o = task._reset_out
+    assert int(o["count"].item()) == want_ids.numel() and int(o["goal_count"].item()) == want_gids.numel()
+    assert_equal(o["env_ids"][: want_ids.numel()], want_ids, "env ids == nonzero()")
+    assert_equal(o["goal_ids"][: want_gids.numel()], want_gids, "goal ids == nonzero()")
+    assert int(task.reset_buf.sum().item()) == 0 and int(task.reset_goal_buf.sum().item()) == 0
