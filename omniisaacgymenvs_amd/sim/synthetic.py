@@ -143,8 +143,8 @@ class SyntheticArticulationView:
         if joint_indices is not None:
             # all envs, a subset of joints (in_hand_manipulation.py:360-362): keep the (N, len(joint_indices)) block
             self.joint_position_targets_subset = (positions, joint_indices)
-        elif indices is None or (count is None and indices.shape[0] == self.count):
-            self.joint_position_targets = positions
+        elif indices is None:
+            self.joint_position_targets.copy_(positions)
         else:
             self._scatter(self.joint_position_targets, positions, indices, count)
 
