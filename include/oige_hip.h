@@ -305,6 +305,113 @@ int oige_hand_reset_target_pose(const oige_hand_params* params, const oige_hand_
                                 const oige_hand_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
                                 oige_stream_t stream);
 
+/* ------------------------------------------------------------------ AnymalTerrain
+ * tasks/anymal_terrain.py.  Scalars: update_config (:85-155), cfg/task/AnymalTerrain.yaml;
+ * terrain constants: tasks/utils/anymal_terrain_generator.py:38-60.                         */
+#define OIGE_ANYMAL_DOFS 12
+#define OIGE_ANYMAL_OBS 188
+#define OIGE_ANYMAL_SCAN_POINTS 140  /* 14 x 10 grid, init_height_points :173-187 */
+#define OIGE_ANYMAL_EPISODE_SUMS 13  /* episode_sums dict order, :68-82 */
+
+/* indices into rew_scales (each already multiplied by dt in double, :140-141) */
+enum {
+  OIGE_AR_TERMINATION = 0, OIGE_AR_LIN_VEL_XY, OIGE_AR_LIN_VEL_Z, OIGE_AR_ANG_VEL_Z, OIGE_AR_ANG_VEL_XY,
+  OIGE_AR_ORIENT, OIGE_AR_TORQUE, OIGE_AR_JOINT_ACC, OIGE_AR_BASE_HEIGHT, OIGE_AR_ACTION_RATE, OIGE_AR_HIP,
+  OIGE_AR_FALLEN_OVER, OIGE_AR_COUNT
+};
+
+typedef struct oige_anymal_params {
+  float lin_vel_scale, ang_vel_scale, dof_pos_scale, dof_vel_scale, height_meas_scale;
+  float action_scale, Kp, Kd;
+  float max_episode_length_s;
+  int32_t max_episode_length;   /* int(20 / dt + 0.5) = 1000 (:132) */
+  int32_t curriculum;           /* update_terrain_level active (:370) */
+  int32_t init_done;            /* (:370) */
+  int32_t add_noise;            /* (:438) */
+  int32_t env_rows, env_cols;   /* terrain levels x types (10 x 20) */
+  int32_t hs_rows, hs_cols;     /* height_samples shape (1200 x 2000) */
+  float horizontal_scale, vertical_scale, border_size, half_env_length;
+  float rew_scales[OIGE_AR_COUNT];
+  float cmd_lo[3], cmd_span[3]; /* x, y, heading: lower and (upper - lower) folded in double (:341-349) */
+  float base_init_state[13];    /* pos, rot wxyz, lin vel, ang vel (:118-123) */
+  float default_dof_pos[OIGE_ANYMAL_DOFS];
+  float noise_scales[6];        /* noise_scale_vec values for cols 0:3, 3:6, 6:9, 12:24, 24:36, 36:176 (:157-171) */
+  float reserved[3];
+} oige_anymal_params;
+
+/* refresh_*_state_tensors (:382-389) + contact forces (:459,:462) + terrain tables; read-only */
+typedef struct oige_anymal_state {
+  const float* base_pos;         /* (N,3) */
+  const float* base_quat;        /* (N,4) */
+  const float* base_velocities;  /* (N,6) */
+  const float* dof_pos;          /* (N,12) */
+  const float* dof_vel;          /* (N,12) */
+  const float* knee_contact;     /* (4N,3) _knees.get_net_contact_forces */
+  const float* base_contact;     /* (N,3)  _base.get_net_contact_forces */
+  const int16_t* height_samples; /* (hs_rows, hs_cols) int16 (:196-198) */
+  const float* terrain_origins;  /* (env_rows, env_cols, 3) (:241) */
+} oige_anymal_state;
+
+typedef struct oige_anymal_buffers {
+  float* obs_buf;            /* (N,188) */
+  float* rew_buf;            /* (N,) */
+  uint8_t* reset_buf;        /* (N,) BOOL: the reference rebinds reset_buf to a bool tensor (:465) */
+  uint8_t* has_fallen;       /* (N,) bool (:462) */
+  int64_t* timeout_buf;      /* (N,) (:453) */
+  int64_t* progress_buf;     /* (N,) */
+  float* commands;           /* (N,4) x vel, y vel, yaw vel, heading (:276) */
+  const float* actions;      /* (N,12) */
+  float* last_actions;       /* (N,12) */
+  float* last_dof_vel;       /* (N,12) */
+  const float* torques;      /* (N,12) last sub-step's torques (:405) */
+  float* feet_air_time;      /* (N,4) */
+  float* episode_sums;       /* (13,N) row k = episode_sums[key k] */
+  int64_t* terrain_levels;   /* (N,) */
+  const int64_t* terrain_types; /* (N,) */
+  float* env_origins;        /* (N,3) */
+  float* extras;             /* (14,) device: 13 x rew_<key> means / max_episode_length_s, terrain_level mean (:361-367) */
+  int32_t* reset_workspace;  /* oige_workspace_ints(N) */
+  float* reduce_workspace;   /* 16 * oige_num_tiles(N) + 4 floats */
+} oige_anymal_buffers;
+
+/* reset rows for the view setters (:334-339), compacted in ascending env order */
+typedef struct oige_anymal_reset_io {
+  const float* u_dof_offset; /* NULL or (n,12) U[0,1): 1st draw (:321) */
+  const float* u_dof_vel;    /* (n,12) 2nd draw (:322) */
+  const float* u_xy;         /* (n,2) 3rd draw (:330) */
+  const float* u_cmd;        /* (n,3) 4th-6th draws: x, y, heading (:341-349) */
+  const float* noise_u;      /* NULL or (N,188) U[0,1) replacing torch.rand_like (:439) */
+  const uint8_t* reset_mask; /* oige_anymal_reset_idx only: (N,) 1 where env is in env_ids */
+  uint64_t seed;
+  uint64_t step;
+  int64_t* env_ids;          /* out (N,) == reset_buf.nonzero().flatten() (:433) */
+  int64_t* count;            /* out device scalar */
+  float* base_pos_out;       /* out (n,3) */
+  float* base_quat_out;      /* out (n,4) */
+  float* base_vel_out;       /* out (n,6) */
+  float* dof_pos_out;        /* out (n,12) */
+  float* dof_vel_out;        /* out (n,12) */
+} oige_anymal_reset_io;
+
+/* One decimation sub-step of pre_physics_step (:398-403):
+ * torques = clip(Kp*(action_scale*actions + default_dof_pos - dof_pos) - Kd*dof_vel, -80, 80)   */
+int oige_anymal_torques(const oige_anymal_params* params, const float* actions, const float* dof_pos,
+                        const float* dof_vel, float* torques_out, int64_t num_envs, oige_stream_t stream);
+
+/* post_physics_step (:409-444) in the reference's order: progress += 1; body-frame velocities,
+ * projected gravity, heading command (:421-427); check_termination (:452-466); calculate_metrics
+ * (:468-533); the in-step reset_idx of the flagged envs (:433-435, :318-380); get_observations with
+ * the height scan (:535-604); uniform observation noise (:438-439); last_* copies (:441-442).   */
+int oige_anymal_post_physics(const oige_anymal_params* params, const oige_anymal_state* state,
+                             const oige_anymal_buffers* buffers, const oige_anymal_reset_io* reset_io,
+                             int64_t num_envs, oige_stream_t stream);
+
+/* reset_idx(env_ids) on its own (:318-367; post_reset :314-315 calls it with every env and
+ * init_done = 0): env_ids are given as the byte mask reset_io->reset_mask; same outputs.          */
+int oige_anymal_reset_idx(const oige_anymal_params* params, const oige_anymal_state* state,
+                          const oige_anymal_buffers* buffers, const oige_anymal_reset_io* reset_io,
+                          int64_t num_envs, oige_stream_t stream);
+
 /* ------------------------------------------------------------------ Cartpole
  * tasks/cartpole.py:91-164.                                                                 */
 typedef struct oige_cartpole_params {

@@ -117,6 +117,44 @@ class HandResetIO(C.Structure):
 HAND_OBS_OPENAI, HAND_OBS_FULL = 0, 2
 
 
+AR_TERMINATION, AR_LIN_VEL_XY, AR_LIN_VEL_Z, AR_ANG_VEL_Z, AR_ANG_VEL_XY, AR_ORIENT, AR_TORQUE, AR_JOINT_ACC, \
+    AR_BASE_HEIGHT, AR_ACTION_RATE, AR_HIP, AR_FALLEN_OVER, AR_COUNT = range(13)
+
+
+class AnymalParams(C.Structure):
+    _fields_ = [
+        ("lin_vel_scale", _f), ("ang_vel_scale", _f), ("dof_pos_scale", _f), ("dof_vel_scale", _f),
+        ("height_meas_scale", _f), ("action_scale", _f), ("Kp", _f), ("Kd", _f), ("max_episode_length_s", _f),
+        ("max_episode_length", C.c_int32), ("curriculum", C.c_int32), ("init_done", C.c_int32), ("add_noise", C.c_int32),
+        ("env_rows", C.c_int32), ("env_cols", C.c_int32), ("hs_rows", C.c_int32), ("hs_cols", C.c_int32),
+        ("horizontal_scale", _f), ("vertical_scale", _f), ("border_size", _f), ("half_env_length", _f),
+        ("rew_scales", _f * 12), ("cmd_lo", _f * 3), ("cmd_span", _f * 3), ("base_init_state", _f * 13),
+        ("default_dof_pos", _f * 12), ("noise_scales", _f * 6), ("reserved", _f * 3),
+    ]
+
+
+class AnymalState(C.Structure):
+    _fields_ = [(n, _fp) for n in (
+        "base_pos", "base_quat", "base_velocities", "dof_pos", "dof_vel", "knee_contact", "base_contact",
+        "height_samples", "terrain_origins")]
+
+
+class AnymalBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in (
+        "obs_buf", "rew_buf", "reset_buf", "has_fallen", "timeout_buf", "progress_buf", "commands", "actions",
+        "last_actions", "last_dof_vel", "torques", "feet_air_time", "episode_sums", "terrain_levels", "terrain_types",
+        "env_origins", "extras", "reset_workspace", "reduce_workspace")]
+
+
+class AnymalResetIO(C.Structure):
+    _fields_ = [
+        ("u_dof_offset", _fp), ("u_dof_vel", _fp), ("u_xy", _fp), ("u_cmd", _fp), ("noise_u", _fp), ("reset_mask", _fp),
+        ("seed", C.c_uint64), ("step", C.c_uint64),
+        ("env_ids", _fp), ("count", _fp), ("base_pos_out", _fp), ("base_quat_out", _fp), ("base_vel_out", _fp),
+        ("dof_pos_out", _fp), ("dof_vel_out", _fp),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/oige_hip.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -146,6 +184,11 @@ SIGNATURES = {
                                       C.c_int64, _P]),
     "oige_hand_reset_target_pose": (C.c_int, [C.POINTER(HandParams), C.POINTER(HandBuffers), C.POINTER(HandResetIO),
                                               C.c_int64, C.c_int64, _P]),
+    "oige_anymal_torques": (C.c_int, [C.POINTER(AnymalParams), _P, _P, _P, _P, C.c_int64, _P]),
+    "oige_anymal_post_physics": (C.c_int, [C.POINTER(AnymalParams), C.POINTER(AnymalState), C.POINTER(AnymalBuffers),
+                                           C.POINTER(AnymalResetIO), C.c_int64, _P]),
+    "oige_anymal_reset_idx": (C.c_int, [C.POINTER(AnymalParams), C.POINTER(AnymalState), C.POINTER(AnymalBuffers),
+                                        C.POINTER(AnymalResetIO), C.c_int64, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

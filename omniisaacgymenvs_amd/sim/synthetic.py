@@ -194,3 +194,15 @@ class SyntheticRigidPrimView:
 
     def set_velocities(self, velocities: Tensor, indices=None, count=None) -> None:
         self._scatter(self.velocities, velocities, indices, count)
+
+
+class SyntheticContactView(SyntheticRigidPrimView):
+    """RigidPrimView with ``track_contact_forces=True`` as AnymalView's ``_knees`` / ``_base`` are used
+    (tasks/anymal_terrain.py:389,459,462): world poses plus net contact forces (count, 3)."""
+
+    def __init__(self, name: str, count: int, device, apply_resets: bool = True) -> None:
+        super().__init__(name, count, device, apply_resets)
+        self.net_contact_forces = torch.zeros((count, 3), dtype=torch.float32, device=self._device)
+
+    def get_net_contact_forces(self, clone: bool = True) -> Tensor:
+        return self.net_contact_forces.clone() if clone else self.net_contact_forces

@@ -129,3 +129,58 @@ def load_hand_state(task, st: Dict[str, Tensor]) -> None:
     task.progress_buf.copy_(st["progress"].to(dev))
     task.reset_buf.copy_(st["reset"].to(dev))
     task.reset_goal_buf.copy_(st["reset_goal"].to(dev))
+
+
+ANYMAL_EPISODE_KEYS = 13
+
+
+def anymal_state(n: int, terrain_origins: Tensor, default_dof_pos: Tensor, device="cpu", seed: int = 1234) -> Dict[str, Tensor]:
+    """C5: robots spread over the terrain patches they are assigned to (so the curriculum's
+    distance test goes both ways), z in U(0.3,0.9), contact forces |N(0,0.7)| / |N(0,0.5)| (~15 % fall),
+    commands per AnymalTerrain.yaml:33-37, progress up to the episode length."""
+    g = _gen(device, seed)
+    f = dict(device=device, dtype=torch.float32, generator=g)
+    terrain_origins = terrain_origins.to(device)
+    rows, cols = terrain_origins.shape[0], terrain_origins.shape[1]
+    levels = torch.randint(0, rows, (n,), device=device, generator=g, dtype=torch.int64)
+    types = torch.randint(0, cols, (n,), device=device, generator=g, dtype=torch.int64)
+    env_origins = terrain_origins[levels, types].clone()
+    base_pos = env_origins + torch.cat([torch.rand(n, 2, **f) * 10.0 - 5.0, torch.rand(n, 1, **f) * 0.6 + 0.3], dim=-1)
+    quat = torch.randn(n, 4, **f)
+    quat = (quat / quat.norm(dim=-1, keepdim=True)).contiguous()
+    commands = torch.cat([torch.rand(n, 2, **f) * 2.0 - 1.0, torch.zeros(n, 1, device=device),
+                          torch.rand(n, 1, **f) * 6.28 - 3.14], dim=-1).contiguous()
+    return dict(
+        base_pos=base_pos.contiguous(), base_quat=quat, base_vel=torch.randn(n, 6, **f),
+        dof_pos=(default_dof_pos.to(device)[:1] + torch.randn(n, 12, **f) * 0.3).contiguous(),
+        dof_vel=torch.randn(n, 12, **f) * 2.0,
+        knee_contact=torch.randn(4 * n, 3, **f).abs() * 0.7, base_contact=torch.randn(n, 3, **f).abs() * 0.5,
+        commands=commands, actions=torch.rand(n, 12, **f) * 2.0 - 1.0, last_actions=torch.rand(n, 12, **f) * 2.0 - 1.0,
+        last_dof_vel=torch.randn(n, 12, **f) * 2.0, torques=torch.randn(n, 12, **f) * 30.0,
+        feet_air_time=torch.rand(n, 4, **f), episode_sums=torch.rand(ANYMAL_EPISODE_KEYS, n, **f),
+        terrain_levels=levels, terrain_types=types, env_origins=env_origins.contiguous(),
+        progress=torch.randint(0, 1001, (n,), device=device, generator=g, dtype=torch.int64),
+    )
+
+
+def load_anymal_state(task, st: Dict[str, Tensor]) -> None:
+    dev = task.device
+    v = task._anymals
+    v.positions.copy_(st["base_pos"].to(dev))
+    v.orientations.copy_(st["base_quat"].to(dev))
+    v.velocities.copy_(st["base_vel"].to(dev))
+    v.joint_positions.copy_(st["dof_pos"].to(dev))
+    v.joint_velocities.copy_(st["dof_vel"].to(dev))
+    v._knees.net_contact_forces.copy_(st["knee_contact"].to(dev))
+    v._base.net_contact_forces.copy_(st["base_contact"].to(dev))
+    task.commands.copy_(st["commands"].to(dev))
+    task.actions.copy_(st["actions"].to(dev))
+    task.last_actions.copy_(st["last_actions"].to(dev))
+    task.last_dof_vel.copy_(st["last_dof_vel"].to(dev))
+    task.torques.copy_(st["torques"].to(dev))
+    task.feet_air_time.copy_(st["feet_air_time"].to(dev))
+    task._episode_sums.copy_(st["episode_sums"].to(dev))
+    task.terrain_levels.copy_(st["terrain_levels"].to(dev))
+    task.terrain_types.copy_(st["terrain_types"].to(dev))
+    task.env_origins.copy_(st["env_origins"].to(dev))
+    task.progress_buf.copy_(st["progress"].to(dev))

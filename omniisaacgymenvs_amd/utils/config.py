@@ -112,6 +112,41 @@ _OPENAI_FF_ENV.update({
 TASK_DEFAULTS["ShadowHandOpenAI_FF"] = {"name": "ShadowHand", "env": _OPENAI_FF_ENV, "sim": dict(_SIM),
                                        "domain_randomization": copy.deepcopy(_SHADOW_HAND_DR)}
 
+# cfg/task/AnymalTerrain.yaml:5-103
+TASK_DEFAULTS["AnymalTerrain"] = {
+    "name": "AnymalTerrain",
+    "env": {
+        "numEnvs": 2048, "numObservations": 188, "numActions": 12, "envSpacing": 3.0,
+        "terrain": {
+            "staticFriction": 1.0, "dynamicFriction": 1.0, "restitution": 0.0, "curriculum": True, "maxInitMapLevel": 0,
+            "mapLength": 8.0, "mapWidth": 8.0, "numLevels": 10, "numTerrains": 20,
+            "terrainProportions": [0.1, 0.1, 0.35, 0.25, 0.2], "slopeTreshold": 0.5,
+        },
+        "baseInitState": {"pos": [0.0, 0.0, 0.62], "rot": [1.0, 0.0, 0.0, 0.0], "vLinear": [0.0, 0.0, 0.0],
+                          "vAngular": [0.0, 0.0, 0.0]},
+        "randomCommandVelocityRanges": {"linear_x": [-1.0, 1.0], "linear_y": [-1.0, 1.0], "yaw": [-3.14, 3.14]},
+        "control": {"stiffness": 80.0, "damping": 2.0, "actionScale": 0.5, "decimation": 4},
+        "defaultJointAngles": {
+            "LF_HAA": 0.03, "LH_HAA": 0.03, "RF_HAA": -0.03, "RH_HAA": -0.03,
+            "LF_HFE": 0.4, "LH_HFE": -0.4, "RF_HFE": 0.4, "RH_HFE": -0.4,
+            "LF_KFE": -0.8, "LH_KFE": 0.8, "RF_KFE": -0.8, "RH_KFE": 0.8,
+        },
+        "learn": {
+            "terminalReward": 0.0, "linearVelocityXYRewardScale": 1.0, "linearVelocityZRewardScale": -4.0,
+            "angularVelocityXYRewardScale": -0.05, "angularVelocityZRewardScale": 0.5, "orientationRewardScale": -0.0,
+            "torqueRewardScale": -0.00002, "jointAccRewardScale": -0.0005, "baseHeightRewardScale": -0.0,
+            "actionRateRewardScale": -0.01, "fallenOverRewardScale": -1.0, "hipRewardScale": -0.0,
+            "linearVelocityScale": 2.0, "angularVelocityScale": 0.25, "dofPositionScale": 1.0, "dofVelocityScale": 0.05,
+            "heightMeasurementScale": 5.0,
+            "addNoise": True, "noiseLevel": 1.0, "dofPositionNoise": 0.01, "dofVelocityNoise": 1.5,
+            "linearVelocityNoise": 0.1, "angularVelocityNoise": 0.2, "gravityNoise": 0.05, "heightMeasurementNoise": 0.06,
+            "pushInterval_s": 15, "episodeLength_s": 20,
+        },
+    },
+    "sim": {"dt": 0.005, "add_ground_plane": False, "add_distant_light": False, "enable_cameras": False,
+            "default_physics_material": {"static_friction": 1.0, "dynamic_friction": 1.0, "restitution": 0.0}},
+}
+
 
 def task_config(name: str, num_envs: Optional[int] = None, **env_overrides: Any) -> Dict[str, Any]:
     cfg = copy.deepcopy(TASK_DEFAULTS[name])

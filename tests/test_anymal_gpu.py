@@ -1,0 +1,217 @@
+"""-m gpu parity tests: HIP AnymalTerrain path (through the C ABI) vs the CPU oracle.
+Bar (north_star): reset / timeout / has_fallen flags, reset ids, progress, terrain levels bit-exact;
+fp32 observations, rewards, commands, episode sums, extras within 1e-5 rel / 1e-6 abs."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close, assert_equal, make_task
+from omniisaacgymenvs_amd.sim import workloads
+from oracle import anymal_terrain_oracle as ao
+from oracle import philox
+
+pytestmark = pytest.mark.gpu
+
+
+def _spec(task) -> ao.AnymalSpec:
+    return ao.AnymalSpec(curriculum=bool(task.curriculum), add_noise=bool(task.add_noise))
+
+
+def _loaded(n, seed=1234, **over):
+    env, task = make_task("AnymalTerrain", n, **over)
+    st = workloads.anymal_state(n, task.terrain_origins.cpu(), task.default_dof_pos.cpu(), device="cpu", seed=seed)
+    if n > 8:  # scan points that clip at the map border / negative coordinates; progress straddling the timeout
+        st["base_pos"][0] = torch.tensor([-20.3, -19.95, 0.5])
+        st["base_pos"][1] = torch.tensor([99.9, 180.2, 0.5])
+        st["base_pos"][2] = torch.tensor([-25.0, 300.0, 0.5])
+        st["progress"][3:7] = torch.tensor([997, 998, 999, 1000])
+    workloads.load_anymal_state(task, st)
+    return env, task, st
+
+
+def _oracle_inputs(task, st):
+    s = ao.AnymalState(st["base_pos"].clone(), st["base_quat"].clone(), st["base_vel"].clone(), st["dof_pos"].clone(),
+                       st["dof_vel"].clone(), st["knee_contact"].clone(), st["base_contact"].clone())
+    n = st["base_pos"].shape[0]
+    b = ao.AnymalBuffers(
+        obs_buf=torch.zeros(n, 188), rew_buf=torch.zeros(n), reset_buf=torch.ones(n, dtype=torch.long),
+        timeout_buf=torch.zeros(n, dtype=torch.long), progress_buf=st["progress"].clone(), commands=st["commands"].clone(),
+        actions=st["actions"].clone(), last_actions=st["last_actions"].clone(), last_dof_vel=st["last_dof_vel"].clone(),
+        torques=st["torques"].clone(), feet_air_time=st["feet_air_time"].clone(),
+        episode_sums={k: st["episode_sums"][i].clone() for i, k in enumerate(ao.EPISODE_KEYS)},
+        terrain_levels=st["terrain_levels"].clone(), terrain_types=st["terrain_types"].clone(),
+        env_origins=st["env_origins"].clone(), default_dof_pos=task.default_dof_pos.cpu().clone())
+    return s, b
+
+
+def _philox_draws(seed, step):
+    def draw(ids):
+        u = torch.from_numpy(philox.uniforms(ids.numpy(), 29, seed, step, stream=1))
+        return ao.AnymalResetDraws(u[:, 0:12], u[:, 12:24], u[:, 24:26], u[:, 26:27], u[:, 27:28], u[:, 28:29])
+    return draw
+
+
+def _philox_noise(n, seed, step):
+    """U[0,1) the kernel draws for obs element i: word i % 4 of block (i // 4) on stream 3."""
+    gf = np.arange(n * 188 // 4, dtype=np.uint64)
+    w = philox.philox4x32_10(gf & philox.MASK, (gf >> np.uint64(32)) | np.uint64(3 << 16), np.uint64(step & 0xFFFFFFFF),
+                             np.uint64(step >> 32), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u = np.stack([philox.u01(x) for x in w], axis=-1).reshape(n, 188)
+    return torch.from_numpy(u)
+
+
+def _compare(task, b, env_ids, view, n):
+    o = task._reset_out
+    k = int(o["count"].item())
+    assert k == len(env_ids)
+    assert_equal(o["env_ids"][:k], env_ids, "env_ids == reset_buf.nonzero()")
+    assert task.reset_buf.dtype == torch.bool and b.reset_buf.dtype == torch.bool
+    assert_equal(task.reset_buf, b.reset_buf, "reset_buf")
+    assert_equal(task.timeout_buf, b.timeout_buf, "timeout_buf")
+    assert_equal(task.progress_buf, b.progress_buf, "progress_buf")
+    assert_equal(task.terrain_levels, b.terrain_levels, "terrain_levels")
+    assert_equal(task.env_origins, b.env_origins, "env_origins")
+    assert_equal(task.feet_air_time, b.feet_air_time, "feet_air_time")
+    assert_equal(task.last_actions, b.last_actions, "last_actions")
+    assert_close(task.last_dof_vel, b.last_dof_vel, "last_dof_vel")
+    assert_close(task.commands, b.commands, "commands")
+    assert_close(task.rew_buf, b.rew_buf, "rew_buf")
+    assert_close(task.obs_buf, b.obs_buf, "obs_buf")
+    for i, key in enumerate(ao.EPISODE_KEYS):
+        assert_close(task.episode_sums[key], b.episode_sums[key], "episode_sums." + key)
+    if k > 0:
+        for key in ao.EPISODE_KEYS:
+            assert_close(task.extras["episode"]["rew_" + key].reshape(1), b.extras["episode"]["rew_" + key].reshape(1),
+                         "extras.rew_" + key)
+        assert_close(task.extras["episode"]["terrain_level"].reshape(1), b.extras["episode"]["terrain_level"].reshape(1),
+                     "extras.terrain_level")
+        assert_close(o["base_pos"][:k], view["base_pos"][env_ids], "reset rows base_pos")
+        assert_equal(o["base_quat"][:k], view["base_quat"][env_ids], "reset rows base_quat")
+        assert_equal(o["base_vel"][:k], view["base_velocities"][env_ids], "reset rows base_vel")
+        assert_close(o["dof_pos"][:k], view["dof_pos"][env_ids], "reset rows dof_pos")
+        assert_close(o["dof_vel"][:k], view["dof_vel"][env_ids], "reset rows dof_vel")
+
+
+@pytest.mark.parametrize("n", [1, 40, 64, 257, 4096])
+@pytest.mark.parametrize("noise", ["philox", "given", "off"])
+def test_post_physics_matches_oracle(n, noise):
+    env, task, st = _loaded(n)
+    task._anymals.apply_resets = False  # keep the view buffers as loaded; the rows are compared instead
+    task.add_noise = noise != "off"
+    spec = _spec(task)
+    s, b = _oracle_inputs(task, st)
+    seed, step = task._rand_seed, task._step_count + 1
+    given = torch.rand(n, 188, generator=torch.Generator().manual_seed(9)) if noise == "given" else None
+    noise_u = given if noise == "given" else (_philox_noise(n, seed, step) if noise == "philox" else None)
+    env_ids, view = ao.post_physics(spec, b, s, task.height_samples.cpu(), task.terrain_origins.cpu(),
+                                    draw=_philox_draws(seed, step), noise_u=noise_u)
+    task.post_physics_step(noise_u=given.to(task.device) if given is not None else None)
+    torch.cuda.synchronize()
+    knees = (torch.norm(st["knee_contact"].view(n, 4, 3), dim=-1) > 1.0).sum(-1) > 1.0
+    assert_equal(task.has_fallen, (torch.norm(st["base_contact"], dim=1) > 1.0) | knees, "has_fallen")
+    _compare(task, b, env_ids, view, n)
+
+
+def test_second_step_uses_the_reset_rows_and_new_draws():
+    """Two steps in a row with the setters applied: the second step starts from the first one's reset rows."""
+    n = 300
+    env, task, st = _loaded(n)
+    spec = _spec(task)
+    s, b = _oracle_inputs(task, st)
+    hs, origins = task.height_samples.cpu(), task.terrain_origins.cpu()
+    seed = task._rand_seed
+    for it in range(2):
+        step = task._step_count + 1
+        env_ids, view = ao.post_physics(spec, b, s, hs, origins, draw=_philox_draws(seed, step),
+                                        noise_u=_philox_noise(n, seed, step))
+        task.post_physics_step()
+        torch.cuda.synchronize()
+        _compare(task, b, env_ids, view, n)
+        # the oracle's view copies are what PhysX would now hold
+        s = ao.AnymalState(view["base_pos"], view["base_quat"], view["base_velocities"], view["dof_pos"], view["dof_vel"],
+                           s.knee_contact, s.base_contact)
+        assert_close(task._anymals.joint_positions, view["dof_pos"], "view dof_pos after setters")
+        assert_close(task._anymals.positions, view["base_pos"], "view base_pos after setters")
+
+
+def test_reset_idx_uses_torch_draws_like_the_reference():
+    n = 500
+    env, task, st = _loaded(n)
+    spec = _spec(task)
+    s, b = _oracle_inputs(task, st)
+    b.reset_buf = torch.zeros(n, dtype=torch.bool)
+    task.reset_buf = torch.zeros(n, dtype=torch.bool, device=task.device)
+    ids = torch.tensor([0, 1, 63, 64, 255, 256, 499])
+    torch.manual_seed(77)
+    task.reset_idx(ids.to(task.device))
+    torch.cuda.synchronize()
+    torch.manual_seed(77)
+    k, dev = len(ids), task.device
+    d = ao.AnymalResetDraws(*(torch.rand(k, w, device=dev).cpu() for w in (12, 12, 2, 1, 1, 1)))
+    view = dict(base_pos=s.base_pos.clone(), base_quat=s.base_quat.clone(), base_velocities=s.base_velocities.clone(),
+                dof_pos=s.dof_pos.clone(), dof_vel=s.dof_vel.clone())
+    ao.reset_idx(spec, b, view, ids, d, task.terrain_origins.cpu())
+    assert_equal(task.reset_buf, b.reset_buf, "reset_buf")
+    assert_equal(task.progress_buf, b.progress_buf, "progress_buf")
+    assert_equal(task.terrain_levels, b.terrain_levels, "terrain_levels")
+    assert_equal(task.env_origins, b.env_origins, "env_origins")
+    assert_close(task.commands, b.commands, "commands")
+    assert_equal(task.last_actions, b.last_actions, "last_actions")
+    assert_equal(task.last_dof_vel, b.last_dof_vel, "last_dof_vel")
+    assert_equal(task.feet_air_time, b.feet_air_time, "feet_air_time")
+    for key in ao.EPISODE_KEYS:
+        assert_equal(task.episode_sums[key], b.episode_sums[key], "episode_sums." + key)
+        assert_close(task.extras["episode"]["rew_" + key].reshape(1), b.extras["episode"]["rew_" + key].reshape(1), "extras." + key)
+    assert_close(task._anymals.joint_positions, view["dof_pos"], "view dof_pos")
+    assert_close(task._anymals.joint_velocities, view["dof_vel"], "view dof_vel")
+    assert_close(task._anymals.positions, view["base_pos"], "view base_pos")
+    assert_equal(task._anymals.orientations, view["base_quat"], "view base_quat")
+    assert_equal(task._anymals.velocities, view["base_velocities"], "view base_velocities")
+
+
+def test_post_reset_state_matches_reference_semantics():
+    env, task = make_task("AnymalTerrain", 200)
+    assert task.init_done and int(task.progress_buf.sum().item()) == 0
+    assert_equal(task.env_origins, task.terrain_origins[task.terrain_levels, task.terrain_types], "env_origins (init: no curriculum move)")
+    dp = task._anymals.joint_positions / task.default_dof_pos
+    assert bool(((dp >= 0.5) & (dp <= 1.5)).all())
+    assert bool((task._anymals.orientations == torch.tensor([1.0, 0, 0, 0], device=task.device)).all())
+    off = (task._anymals.positions - task.env_origins)[:, :2]
+    assert bool((off.abs() <= 0.5).all()) and bool(((task._anymals.positions - task.env_origins)[:, 2] - 0.62).abs().max() < 1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 64, 1000])
+def test_pd_torques_match_oracle(n):
+    env, task, st = _loaded(n)
+    spec = _spec(task)
+    task.decimation = 1
+    task.pre_physics_step(st["actions"].to(task.device))
+    torch.cuda.synchronize()
+    want = ao.pd_torques(spec, st["actions"], task.default_dof_pos.cpu(), st["dof_pos"], st["dof_vel"])
+    assert_close(task.torques, want, "torques")
+    assert_equal(task._anymals.joint_efforts, task.torques.cpu(), "efforts handed to the view")
+
+
+def test_full_size_properties():
+    """C5 per-GPU size (2M envs / 8 GPUs = 262144): pass-through columns, reset ids == nonzero(), flags' closed forms."""
+    n = 1 << 18
+    env, task, st = _loaded(n)
+    task._anymals.apply_resets = False
+    task.post_physics_step()
+    torch.cuda.synchronize()
+    obs = task.obs_buf
+    assert_equal(obs[:, 176:188], st["actions"], "obs actions")
+    assert bool((obs[:, 36:176].abs() <= 5.0 + 0.06 * 5.0 + 1e-6).all())
+    assert_equal(task.last_actions, st["actions"], "last_actions")
+    timeout = st["progress"] + 1 >= 999
+    assert_equal(task.timeout_buf, timeout.long(), "timeout_buf")
+    knees = (st["knee_contact"].view(n, 4, 3).norm(dim=-1) > 1.0).sum(-1) > 1
+    fallen = (st["base_contact"].norm(dim=-1) > 1.0) | knees
+    assert_equal(task.reset_buf, fallen | timeout, "reset_buf closed form")
+    ids = task.reset_buf.nonzero().flatten()
+    o = task._reset_out
+    assert int(o["count"].item()) == ids.numel()
+    assert_equal(o["env_ids"][: ids.numel()], ids, "env_ids == nonzero()")
+    assert int(task.progress_buf[ids].sum().item()) == 0
+    assert_equal(task.progress_buf[~task.reset_buf], (st["progress"] + 1)[~task.reset_buf.cpu()], "progress of live envs")
+    assert bool((task.rew_buf >= 0).all())
