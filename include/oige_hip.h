@@ -412,6 +412,54 @@ int oige_anymal_reset_idx(const oige_anymal_params* params, const oige_anymal_st
                           const oige_anymal_buffers* buffers, const oige_anymal_reset_io* reset_io,
                           int64_t num_envs, oige_stream_t stream);
 
+/* ------------------------------------------------------------------ observation / action noise
+ * utils/domain_randomization/randomize.py:283-410 (the part of Randomizer that is task math).      */
+#define OIGE_NOISE_ADDITIVE 0
+#define OIGE_NOISE_SCALING 1
+#define OIGE_NOISE_GAUSSIAN 0   /* "gaussian" / "normal": torch.normal(mean=p[0], std=p[1]) (:345-351) */
+#define OIGE_NOISE_UNIFORM 1    /* (p[1] - p[0]) * rand + p[0]                              (:352-355) */
+#define OIGE_NOISE_LOGUNIFORM 2 /* exp((log p[1] - log p[0]) * rand + log p[0])            (:356-361) */
+
+typedef struct oige_noise_term {
+  int32_t enabled;            /* the "on_reset" / "on_interval" key is present (:288,:298) */
+  int32_t operation;          /* OIGE_NOISE_ADDITIVE | OIGE_NOISE_SCALING */
+  int32_t distribution;       /* OIGE_NOISE_* */
+  int32_t frequency_interval; /* on_interval only (:300) */
+  float p0;                   /* gaussian: mean; uniform: p[0]; loguniform: log(p[0]) */
+  float p1;                   /* gaussian: std;  uniform: p[1] - p[0]; loguniform: log(p[1]) - log(p[0]) (folded in double, like Python) */
+} oige_noise_term;
+
+typedef struct oige_noise_args {
+  float* buffer;                 /* (N,W) observations or actions, noised IN PLACE (:289,:305) */
+  const int64_t* reset_buf;      /* (N,) the task's post-is_done reset_buf (vec_env_rlgames.py:72-75,94-97) */
+  int32_t* counter;              /* (N,) int32 _observations/_actions_counter_buffer (:242-244) */
+  float* correlated_noise;       /* (N,W) _observations/_actions_correlated_noise (:245-247); NULL if no on_reset */
+  float* clamped_out;            /* NULL, or (N,W): clamp(buffer, -clip, clip), the copy VecEnvRLGames hands the policy (:40) */
+  const float* reset_samples;    /* NULL -> in-kernel Philox; else (k,W) rows in reset_ids order (:381-400) */
+  const float* interval_samples; /* NULL -> in-kernel Philox; else (m,W) rows in randomize_ids order (:346-361) */
+  int32_t* reset_workspace;      /* oige_workspace_ints(N) each; needed only with pre-drawn samples: */
+  int32_t* interval_workspace;   /*   oige_dr_noise_count leaves counts, group offsets and the totals k, m there */
+  uint64_t seed;
+  uint64_t step;
+  int32_t stream_id;             /* 0 observations, 1 actions: separates the Philox streams */
+  int32_t width;                 /* W */
+  float clip;
+  float reserved0;
+  oige_noise_term on_reset;
+  oige_noise_term on_interval;
+} oige_noise_args;
+
+/* First half of the exact-replay flow: decides reset ids (:284) and randomize ids (:299-303) WITHOUT
+ * touching the counter and leaves their compaction ranks in the two workspaces; the totals k and m are
+ * workspace[oige_workspace_ints(N) - 1] (the caller reads them to size its torch draws, as the
+ * reference's len() does).                                                                       */
+int oige_dr_noise_count(const oige_noise_args* args, int64_t num_envs, oige_stream_t stream);
+
+/* apply_observations_randomization / apply_actions_randomization (:283-342): counter update, correlated
+ * noise refresh of the reset envs + application to all envs, uncorrelated noise of the randomize ids,
+ * and optionally the clamped copy.  One launch.                                                   */
+int oige_dr_noise_apply(const oige_noise_args* args, int64_t num_envs, oige_stream_t stream);
+
 /* ------------------------------------------------------------------ Cartpole
  * tasks/cartpole.py:91-164.                                                                 */
 typedef struct oige_cartpole_params {

@@ -155,6 +155,23 @@ class AnymalResetIO(C.Structure):
     ]
 
 
+NOISE_ADDITIVE, NOISE_SCALING = 0, 1
+NOISE_GAUSSIAN, NOISE_UNIFORM, NOISE_LOGUNIFORM = 0, 1, 2
+
+
+class NoiseTerm(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("operation", C.c_int32), ("distribution", C.c_int32),
+                ("frequency_interval", C.c_int32), ("p0", _f), ("p1", _f)]
+
+
+class NoiseArgs(C.Structure):
+    _fields_ = [(n, _fp) for n in (
+        "buffer", "reset_buf", "counter", "correlated_noise", "clamped_out", "reset_samples", "interval_samples",
+        "reset_workspace", "interval_workspace")] + [
+        ("seed", C.c_uint64), ("step", C.c_uint64), ("stream_id", C.c_int32), ("width", C.c_int32), ("clip", _f),
+        ("reserved0", _f), ("on_reset", NoiseTerm), ("on_interval", NoiseTerm)]
+
+
 # name -> (restype, argtypes); every symbol include/oige_hip.h declares
 _P = C.c_void_p
 SIGNATURES = {
@@ -184,6 +201,8 @@ SIGNATURES = {
                                       C.c_int64, _P]),
     "oige_hand_reset_target_pose": (C.c_int, [C.POINTER(HandParams), C.POINTER(HandBuffers), C.POINTER(HandResetIO),
                                               C.c_int64, C.c_int64, _P]),
+    "oige_dr_noise_count": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
+    "oige_dr_noise_apply": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_anymal_torques": (C.c_int, [C.POINTER(AnymalParams), _P, _P, _P, _P, C.c_int64, _P]),
     "oige_anymal_post_physics": (C.c_int, [C.POINTER(AnymalParams), C.POINTER(AnymalState), C.POINTER(AnymalBuffers),
                                            C.POINTER(AnymalResetIO), C.c_int64, _P]),

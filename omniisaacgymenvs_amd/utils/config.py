@@ -152,6 +152,9 @@ def task_config(name: str, num_envs: Optional[int] = None, **env_overrides: Any)
     cfg = copy.deepcopy(TASK_DEFAULTS[name])
     if num_envs is not None:
         cfg["env"]["numEnvs"] = int(num_envs)
+    for top in ("domain_randomization", "sim"):  # top-level sections of the task YAML; the rest is env.*
+        if top in env_overrides:
+            cfg[top] = copy.deepcopy(env_overrides.pop(top))
     cfg["env"].update(env_overrides)
     return cfg
 

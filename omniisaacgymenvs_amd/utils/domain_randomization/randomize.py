@@ -88,20 +88,30 @@ class Randomizer:
         self._actions_step = 0
 
     # ------------------------------------------------------------------ per-step noise (:283-410)
-    def apply_observations_randomization(self, observations, reset_buf):
+    # ``sync_free`` (default): samples from in-kernel Philox, no host sync.  ``sync_free = False``: the reference's
+    # flow with torch's RNG (ids compacted on the device, counts read back, torch.normal / torch.rand draws).
+    sync_free = True
+
+    def apply_observations_randomization(self, observations, reset_buf, clamped_out=None, clip=float("inf")):
         from . import noise_hip
 
+        if not hasattr(self, "_observations_noise_state"):
+            self._observations_noise_state = noise_hip.NoiseState(observations.shape[0], observations.device)
         self._observations_step += 1
         return noise_hip.apply(
             observations, reset_buf, self._observations_counter_buffer, self._observations_correlated_noise,
-            self._observations_dr_params, seed=int(self._config.get("seed", 0)), stream_id=0, step=self._observations_step,
+            self._observations_dr_params, self._observations_noise_state, seed=int(self._config.get("seed", 0)),
+            stream_id=0, step=self._observations_step, sync_free=self.sync_free, clamped_out=clamped_out, clip=clip,
         )
 
-    def apply_actions_randomization(self, actions, reset_buf):
+    def apply_actions_randomization(self, actions, reset_buf, clamped_out=None, clip=float("inf")):
         from . import noise_hip
 
+        if not hasattr(self, "_actions_noise_state"):
+            self._actions_noise_state = noise_hip.NoiseState(actions.shape[0], actions.device)
         self._actions_step += 1
         return noise_hip.apply(
             actions, reset_buf, self._actions_counter_buffer, self._actions_correlated_noise,
-            self._actions_dr_params, seed=int(self._config.get("seed", 0)), stream_id=1, step=self._actions_step,
+            self._actions_dr_params, self._actions_noise_state, seed=int(self._config.get("seed", 0)),
+            stream_id=1, step=self._actions_step, sync_free=self.sync_free, clamped_out=clamped_out, clip=clip,
         )
