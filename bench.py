@@ -1,21 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- fused obs+reward+reset env-steps/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain]
 
-One "step" = one pre_physics_step (reset-id compaction, reset of the flagged envs, action
-scaling) + one post_physics_step (progress, obs, reward, done) over a batch of synthetic state
-resident in HBM, through the RLTask API -> ctypes -> liboige_hip.so.  Physics is delegated
-(north_star) and not part of the step.  N=1 workload: BASELINE.json configs[1], "Ant
-obs(60)+reward+reset fused kernel, 1M envs synthetic root/DOF state on one MI355X".
-For N>1 every rank owns its own 1M envs (weak scaling; envs are independent, so there is no
-data-path collective); ranks all-reduce a 32-byte episode-statistics vector over RCCL.
+One "step" = one pre_physics_step (reset-id compaction, reset of the flagged envs, action scaling /
+PD torques) + one post_physics_step (progress, obs, reward, done[, in-step reset]) over a batch of
+synthetic state resident in HBM, through the RLTask API -> ctypes -> liboige_hip.so.  With
+``--task ShadowHand`` the wrapper-side observation and action noise (DR) runs too, as BASELINE.json
+configs[3] asks.  Physics is delegated (north_star) and not part of the step.
+N=1 default workload: BASELINE.json configs[1], "Ant obs(60)+reward+reset fused kernel, 1M envs
+synthetic root/DOF state on one MI355X".  For N>1 every rank owns its own --envs envs (weak scaling;
+envs are independent, so there is no data-path collective); ranks all-reduce a 32-byte
+episode-statistics vector over RCCL once per timed region.
 
 Prints ONE JSON line (rank 0).
 """
 from __future__ import annotations
 
 import argparse
+import copy
 import json
 import os
 import sys
@@ -30,38 +33,234 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 
 
-def algorithmic_bytes(d: int, s: int, with_vecs: bool) -> dict:
-    """bytes that must cross HBM once per env-step."""
+# ---------------------------------------------------------------------------- algorithmic bytes
+def locomotion_bytes(d: int, s: int, with_vecs: bool) -> dict:
     obs = 12 + 3 * d + 6 * s
     post_r = 12 + 16 + 24 + 4 * d + 4 * d + 24 * s + 4 * d + 4 + 8 + 8
     post_w = 4 * obs + 4 + 4 + 4 + 8 + 8 + (24 if with_vecs else 0)
-    pre = 4 * d + 4 * d + 4 * d  # actions in, forces out, actions clone out (locomotion.py:125)
-    return {"post": post_r + post_w, "pre": pre, "obs": obs}
+    return {"post": post_r + post_w, "obs": obs}
+
+
+HAND_POST_BYTES = 744 + 28 + 948        # openai obs 42 + asymmetric states 187 + reward/flags
+ANYMAL_POST_BYTES = 512 + 560 + 913     # state + 280 int16 gathers + obs/flags/sums
+
+
+# ---------------------------------------------------------------------------- per-task adapters
+class LocomotionBench:
+    def __init__(self, name, n, dev, seed):
+        from helpers import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+
+        self.name = name
+        self.env, self.task = make_task(name, n, device=dev, seed=seed)
+        t = self.task
+        self.d, self.s = t._robots.num_dof, t._num_sensors
+        z = (0.2, 0.9) if name == "Ant" else (0.5, 1.5)
+        st = workloads.locomotion_state(n, t.dof_limits_lower, t.dof_limits_upper, self.s, device=dev, seed=seed, z_range=z)
+        workloads.load_locomotion_state(t, st)
+        t._robots.apply_resets = False  # PhysX-side scatter is delegated; the kernels still compute every reset row
+        self.actions = st["actions"]
+        ab = locomotion_bytes(self.d, self.s, t.materialize_vecs)
+        self.post_bytes = ab["post"]
+        self.kernel = "locomotion_post_kernel"
+        self.workload = f"{name} obs({ab['obs']})+reward+reset fused, {n} envs per GPU, synthetic root/DOF state"
+        self.extra_cfg = {"num_dof": self.d, "num_sensors": self.s}
+
+    def pre(self):
+        self.task.pre_physics_step(self.actions)
+
+    def post(self):
+        self.task.post_physics_step()
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    def stats(self, out):
+        t = self.task
+        out[0], out[1], out[2] = t.rew_buf.sum(), t.reset_buf.sum(), (t.progress_buf * t.reset_buf).sum()
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from oracle import locomotion_oracle as lo
+
+        spec = lo.ant_spec() if name == "Ant" else lo.humanoid_spec()
+        z = (0.2, 0.9) if name == "Ant" else (0.5, 1.5)
+        st = workloads.locomotion_state(n, spec.dof_limits_lower, spec.dof_limits_upper, spec.num_sensors, "cpu", 1234, z)
+        b = lo.LocomotionBuffers.fresh(spec, n)
+        b.reset_buf[:] = 0
+        b.progress_buf[:] = st["progress"]
+        b.potentials[:] = st["potentials"]
+        init_pos, init_rot = st["pos"].clone(), st["rot"].clone()
+        init_dof = torch.zeros(n, spec.num_dof)
+        g = torch.Generator().manual_seed(0)
+        draw = lambda ids: (torch.rand(len(ids), spec.num_dof, generator=g), torch.rand(len(ids), spec.num_dof, generator=g))
+
+        def step():
+            lo.pre_physics(spec, b, st["actions"], init_pos, init_rot, init_dof, draw=draw)
+            lo.post_physics(spec, b, st["pos"], st["rot"], st["vel"], st["dof_pos"], st["dof_vel"], st["sensors"])
+
+        return step
+
+
+class HandBench:
+    """C4: ShadowHandOpenAI_FF (openai obs + asymmetric full_state states + goal-rotation reward) with DR noise."""
+
+    def __init__(self, name, n, dev, seed):
+        from helpers import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+        from omniisaacgymenvs_amd.utils.config import TASK_DEFAULTS
+
+        dr = copy.deepcopy(TASK_DEFAULTS["ShadowHandOpenAI_FF"]["domain_randomization"])
+        dr["randomize"] = True
+        self.env, self.task = make_task("ShadowHandOpenAI_FF", n, device=dev, seed=seed, domain_randomization=dr)
+        t = self.task
+        st = workloads.hand_state(n, t._env_pos, t.goal_pos, t.hand_dof_lower_limits, t.hand_dof_upper_limits, device=dev, seed=seed)
+        workloads.load_hand_state(t, st)
+        for v in (t._hands, t._objects, t._goals):
+            v.apply_resets = False
+        self.actions = st["actions"]
+        self._noisy = torch.empty_like(self.actions)
+        self.post_bytes = HAND_POST_BYTES
+        self.kernel = "hand_post_kernel"
+        self.workload = (f"ShadowHand openai obs(42) + full_state states(187) + goal-rotation reward + reset_target_pose/reset_idx "
+                         f"+ obs/action DR noise, {n} envs per GPU, synthetic state")
+        self.extra_cfg = {"observationType": t.obs_type, "asymmetric_observations": True, "dr_noise": True}
+
+    def pre(self):
+        t = self.task
+        self._noisy.copy_(self.actions)
+        a = t._dr_randomizer.apply_actions_randomization(actions=self._noisy, reset_buf=t.reset_buf)
+        t.pre_physics_step(a)
+
+    def post(self):
+        t = self.task
+        t.post_physics_step()
+        t._dr_randomizer.apply_observations_randomization(observations=t.obs_buf, reset_buf=t.reset_buf)
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    def stats(self, out):
+        t = self.task
+        out[0], out[1], out[2] = t.rew_buf.sum(), t.reset_buf.sum(), (t.progress_buf * t.reset_buf).sum()
+        out[3] = t.successes.sum()
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from omniisaacgymenvs_amd.tasks.shadow_hand import SHADOW_HAND_ACTUATED, shadow_hand_stand_in_limits
+        from omniisaacgymenvs_amd.utils.config import TASK_DEFAULTS
+        from oracle import dr_noise_oracle as dro
+        from oracle import hand_oracle as ho
+
+        lim = shadow_hand_stand_in_limits()
+        e = TASK_DEFAULTS["ShadowHandOpenAI_FF"]["env"]
+        spec = ho.HandSpec(obs_type="openai", asymmetric_obs=True, fall_penalty=e["fallPenalty"], success_tolerance=e["successTolerance"],
+                           act_moving_average=e["actionsMovingAverage"], max_episode_length=160,
+                           max_consecutive_successes=e["maxConsecutiveSuccesses"], av_factor=e["averFactor"],
+                           actuated_dof_indices=list(SHADOW_HAND_ACTUATED), lower=lim[:, 0].contiguous(), upper=lim[:, 1].contiguous())
+        env_pos = torch.zeros(n, 3)
+        goal_pos = torch.tensor([0.0, -0.39, 0.56]).repeat(n, 1)
+        st = workloads.hand_state(n, env_pos, goal_pos, spec.lower, spec.upper, device="cpu", seed=1234)
+        s = ho.HandState(st["object_pos"], st["object_rot"], st["object_vel"], st["ft_pos"], st["ft_rot"], st["ft_vel"],
+                         st["dof_pos"], st["dof_vel"], st["sensors"], env_pos)
+        b = ho.HandBuffers(torch.zeros(n, 42), torch.zeros(n, 187), torch.zeros(n), st["reset"].clone(), st["reset_goal"].clone(),
+                           st["progress"].clone(), st["successes"].clone(), torch.zeros(1), goal_pos.clone(), st["goal_rot"].clone(),
+                           st["actions"].clone(), torch.zeros(n, 24), torch.zeros(n, 24))
+        init = ho.HandInit(goal_pos.clone(), goal_pos.clone(), env_pos, torch.zeros(24), torch.zeros(24))
+        dr = TASK_DEFAULTS["ShadowHand"]["domain_randomization"]["randomization_params"]
+        oc, occ = torch.zeros(n, dtype=torch.int), torch.zeros(n, 42)
+        ac, acc = torch.zeros(n, dtype=torch.int), torch.zeros(n, 20)
+        u = lambda ids, k: 2.0 * torch.rand(len(ids), k) - 1.0
+
+        def step():
+            a = dro.apply_randomization(st["actions"].clone(), b.reset_buf, ac, acc, dr["actions"])
+            ho.pre_physics(spec, b, init, a, draw_goal=lambda ids: u(ids, 4), draw_reset=lambda ids: (u(ids, 53), u(ids, 4)))
+            ho.post_physics(spec, s, b)
+            dro.apply_randomization(b.obs_buf, b.reset_buf, oc, occ, dr["observations"])
+
+        return step
+
+
+class AnymalBench:
+    """C5 per-GPU shard: AnymalTerrain height-scan obs + 11-term reward + in-step reset."""
+
+    def __init__(self, name, n, dev, seed):
+        from helpers import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+
+        self.env, self.task = make_task("AnymalTerrain", n, device=dev, seed=seed)
+        t = self.task
+        st = workloads.anymal_state(n, t.terrain_origins, t.default_dof_pos, device=dev, seed=seed)
+        workloads.load_anymal_state(t, st)
+        t._anymals.apply_resets = False
+        t.decimation = 1  # one PD-torque sub-step per env-step (the other three belong to the delegated physics loop)
+        self.actions = st["actions"]
+        self.post_bytes = ANYMAL_POST_BYTES
+        self.kernel = "anymal_post_kernel"
+        self.workload = (f"AnymalTerrain height-scan obs(188) + 11-term reward + in-step reset + obs noise, {n} envs per GPU, "
+                         "synthetic state, 1200x2000 int16 heightfield")
+        self.extra_cfg = {"scan_points": 140, "decimation_substeps_timed": 1}
+
+    def pre(self):
+        self.task.pre_physics_step(self.actions)
+
+    def post(self):
+        self.task.post_physics_step()
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    def stats(self, out):
+        t = self.task
+        out[0], out[1], out[2] = t.rew_buf.sum(), t.reset_buf.sum(), (t.progress_buf * t.reset_buf).sum()
+        out[3] = t.terrain_levels.sum()
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from omniisaacgymenvs_amd.sim.terrain import SyntheticTerrain
+        from omniisaacgymenvs_amd.utils.config import TASK_DEFAULTS
+        from oracle import anymal_terrain_oracle as ao
+
+        spec = ao.AnymalSpec()
+        terrain = SyntheticTerrain(TASK_DEFAULTS["AnymalTerrain"]["env"]["terrain"], n)
+        hs = torch.tensor(terrain.heightsamples)
+        origins = torch.from_numpy(terrain.env_origins).float()
+        default = torch.tensor(ao.DEFAULT_JOINT_ANGLES).repeat(n, 1)
+        st = workloads.anymal_state(n, origins, default, device="cpu", seed=1234)
+        s = ao.AnymalState(st["base_pos"], st["base_quat"], st["base_vel"], st["dof_pos"], st["dof_vel"], st["knee_contact"],
+                           st["base_contact"])
+        b = ao.AnymalBuffers(
+            obs_buf=torch.zeros(n, 188), rew_buf=torch.zeros(n), reset_buf=torch.ones(n, dtype=torch.long),
+            timeout_buf=torch.zeros(n, dtype=torch.long), progress_buf=st["progress"].clone(), commands=st["commands"].clone(),
+            actions=st["actions"].clone(), last_actions=st["last_actions"].clone(), last_dof_vel=st["last_dof_vel"].clone(),
+            torques=st["torques"].clone(), feet_air_time=st["feet_air_time"].clone(),
+            episode_sums={k: st["episode_sums"][i].clone() for i, k in enumerate(ao.EPISODE_KEYS)},
+            terrain_levels=st["terrain_levels"].clone(), terrain_types=st["terrain_types"].clone(),
+            env_origins=st["env_origins"].clone(), default_dof_pos=default)
+
+        def draw(ids):
+            k = len(ids)
+            return ao.AnymalResetDraws(torch.rand(k, 12), torch.rand(k, 12), torch.rand(k, 2), torch.rand(k, 1), torch.rand(k, 1),
+                                       torch.rand(k, 1))
+
+        def step():
+            b.torques = ao.pd_torques(spec, b.actions, default, s.dof_pos, s.dof_vel)
+            ao.post_physics(spec, b, s, hs, origins, draw=draw)
+
+        return step
+
+
+ADAPTERS = {"Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
+DEFAULT_ENVS = {"Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
+CPU_ENVS = {"Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
 def cpu_baseline(task_name: str, n: int, budget_s: float = 12.0):
     """The oracle (CPU torch restatement of the reference) timed on the host cores: bounded sample."""
-    from omniisaacgymenvs_amd.sim import workloads
-    from oracle import locomotion_oracle as lo
-
-    spec = lo.ant_spec() if task_name == "Ant" else lo.humanoid_spec()
-    z = (0.2, 0.9) if task_name == "Ant" else (0.5, 1.5)
-    st = workloads.locomotion_state(n, spec.dof_limits_lower, spec.dof_limits_upper, spec.num_sensors, "cpu", 1234, z)
-    b = lo.LocomotionBuffers.fresh(spec, n)
-    b.reset_buf[:] = 0
-    b.progress_buf[:] = st["progress"]
-    b.potentials[:] = st["potentials"]
-    init_pos, init_rot = st["pos"].clone(), st["rot"].clone()
-    init_dof = torch.zeros(n, spec.num_dof)
-    g = torch.Generator().manual_seed(0)
-
-    def draw(ids):
-        return (torch.rand(len(ids), spec.num_dof, generator=g), torch.rand(len(ids), spec.num_dof, generator=g))
-
-    def step():
-        lo.pre_physics(spec, b, st["actions"], init_pos, init_rot, init_dof, draw=draw)
-        lo.post_physics(spec, b, st["pos"], st["rot"], st["vel"], st["dof_pos"], st["dof_vel"], st["sensors"])
-
+    step = ADAPTERS[task_name].cpu_baseline(task_name, n, budget_s)
     step()  # warm-up
     t0 = time.perf_counter()
     k = 0
@@ -73,7 +272,7 @@ def cpu_baseline(task_name: str, n: int, budget_s: float = 12.0):
     dt = (time.perf_counter() - t0) / k
     return {
         "value": n / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": f"{task_name} oracle (CPU torch restatement) pre+post, {n} envs, {k} steps, {dt*1e3:.1f} ms/step",
+        "sample": f"{task_name} oracle (CPU torch restatement of the reference) pre+post, {n} envs, {k} steps, {dt*1e3:.1f} ms/step",
     }
 
 
@@ -82,10 +281,11 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--envs", type=int, default=1 << 20, help="envs per GPU")
-    ap.add_argument("--task", default="Ant", choices=["Ant", "Humanoid"])
+    ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the BASELINE.json config's per-GPU size)")
+    ap.add_argument("--task", default="Ant", choices=list(ADAPTERS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-envs", type=int, default=1 << 18)
+    ap.add_argument("--cpu-envs", type=int, default=0)
+    ap.add_argument("--traffic-json", default="", help="PMC-derived HBM bytes per launch (profiles/*.json) to report as roofline.traffic")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,35 +302,23 @@ def main() -> None:
         torch.cuda.set_device(0)
     dev = f"cuda:{local_rank if world > 1 else 0}"
 
-    from helpers import make_task
-    from omniisaacgymenvs_amd.sim import workloads
-
-    n = args.envs
-    env, task = make_task(args.task, n, device=dev, seed=1234 + rank)
-    d, s = task._robots.num_dof, task._num_sensors
-    z = (0.2, 0.9) if args.task == "Ant" else (0.5, 1.5)
-    st = workloads.locomotion_state(n, task.dof_limits_lower, task.dof_limits_upper, s, device=dev, seed=1234 + rank, z_range=z)
-    workloads.load_locomotion_state(task, st)
-    task._robots.apply_resets = False  # PhysX-side scatter is delegated; the kernels still compute every reset row
-    actions = st["actions"]
+    n = args.envs or DEFAULT_ENVS[args.task]
+    bench = ADAPTERS[args.task](args.task, n, dev, 1234 + rank)
     stats = torch.zeros(8, dtype=torch.float32, device=dev)
-
-    def step():
-        task.pre_physics_step(actions)
-        task.post_physics_step()
 
     ev_pairs = []
 
     def timed_step():
-        task.pre_physics_step(actions)
+        bench.pre()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        task.post_physics_step()
+        e0.record()  # torch's current stream == the stream the kernels are launched on (_lib.current_stream)
+        bench.post()
         e1.record()
         ev_pairs.append((e0, e1))
 
     for _ in range(args.warmup):
-        step()
+        bench.pre()
+        bench.post()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -139,10 +327,8 @@ def main() -> None:
     for _ in range(args.steps):
         timed_step()
     if dist is not None:
-        # episode statistics: [sum reward, n done, sum episode length of done envs, ...] -- 32 bytes
-        stats[0] = task.rew_buf.sum()
-        stats[1] = task.reset_buf.sum()
-        stats[2] = (task.progress_buf * task.reset_buf).sum()
+        # episode statistics: [sum reward, n done, sum episode length of done envs, successes / terrain level] -- 32 bytes
+        bench.stats(stats)
         dist.all_reduce(stats)
     torch.cuda.synchronize()
     if dist is not None:
@@ -155,11 +341,16 @@ def main() -> None:
         elapsed = float(t.item())
 
     post_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
-    ab = algorithmic_bytes(d, s, task.materialize_vecs)
-    achieved = ab["post"] * n / (post_ms * 1e-3) / 1e9
-    resets_per_step = int(task._reset_out["count"].item())
+    achieved = bench.post_bytes * n / (post_ms * 1e-3) / 1e9
+    traffic = None
+    if args.traffic_json and os.path.exists(args.traffic_json):
+        with open(args.traffic_json) as f:
+            traffic = json.load(f).get(args.task, {}).get("hbm_bytes_per_launch")
 
     if rank == 0:
+        cfg = {"workload": bench.workload, "envs_per_gpu": n, "resets_per_step": bench.resets(),
+               "step": "pre_physics_step + post_physics_step via RLTask API (physics delegated)"}
+        cfg.update(bench.extra_cfg)
         out = {
             "metric": "fused obs+reward+reset env-steps/s",
             "value": world * n * args.steps / elapsed,
@@ -173,19 +364,15 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {
-                "workload": f"{args.task} obs({ab['obs']})+reward+reset fused, {n} envs per GPU, synthetic root/DOF state",
-                "envs_per_gpu": n, "num_dof": d, "num_sensors": s, "resets_per_step": resets_per_step,
-                "step": "pre_physics_step + post_physics_step via RLTask API (physics delegated)",
-            },
+            "config": cfg,
             "roofline": {
-                "bound": "hbm", "kernel": "locomotion_post_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_env": ab["post"], "avg_kernel_ms": post_ms,
+                "bound": "hbm", "kernel": bench.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "algorithmic_bytes_per_env": bench.post_bytes, "avg_kernel_ms": post_ms,
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.task, min(n, args.cpu_envs))
+            out["cpu_baseline"] = cpu_baseline(args.task, min(n, args.cpu_envs or CPU_ENVS[args.task]))
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
