@@ -134,8 +134,10 @@ class HandBench:
         t.pre_physics_step(a)
 
     def post(self):
+        self.task.post_physics_step()
+
+    def after_post(self):  # wrapper-side observation noise (vec_env_rlgames.py:94-97); outside the post-kernel event bracket
         t = self.task
-        t.post_physics_step()
         t._dr_randomizer.apply_observations_randomization(observations=t.obs_buf, reset_buf=t.reset_buf)
 
     def resets(self):
@@ -285,7 +287,8 @@ def main() -> None:
     ap.add_argument("--task", default="Ant", choices=list(ADAPTERS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=0)
-    ap.add_argument("--traffic-json", default="", help="PMC-derived HBM bytes per launch (profiles/*.json) to report as roofline.traffic")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
+                    help="PMC-derived HBM bytes per launch of the dominant kernel (profiles/run_profiles.sh) -> roofline.traffic")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -307,6 +310,7 @@ def main() -> None:
     stats = torch.zeros(8, dtype=torch.float32, device=dev)
 
     ev_pairs = []
+    after = getattr(bench, "after_post", lambda: None)
 
     def timed_step():
         bench.pre()
@@ -314,11 +318,13 @@ def main() -> None:
         e0.record()  # torch's current stream == the stream the kernels are launched on (_lib.current_stream)
         bench.post()
         e1.record()
+        after()
         ev_pairs.append((e0, e1))
 
     for _ in range(args.warmup):
         bench.pre()
         bench.post()
+        after()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -345,7 +351,9 @@ def main() -> None:
     traffic = None
     if args.traffic_json and os.path.exists(args.traffic_json):
         with open(args.traffic_json) as f:
-            traffic = json.load(f).get(args.task, {}).get("hbm_bytes_per_launch")
+            rec = json.load(f).get(args.task)
+        if rec:  # measured at rec["envs"] envs per launch; the kernels stream, so bytes scale with the env count
+            traffic = rec["hbm_bytes_per_launch"] * n / rec["envs"]
 
     if rank == 0:
         cfg = {"workload": bench.workload, "envs_per_gpu": n, "resets_per_step": bench.resets(),
