@@ -75,9 +75,6 @@ class LocomotionBench:
     def resets(self):
         return int(self.task._reset_out["count"].item())
 
-    def stats(self, out):
-        t = self.task
-        out[0], out[1], out[2] = t.rew_buf.sum(), t.reset_buf.sum(), (t.progress_buf * t.reset_buf).sum()
 
     @staticmethod
     def cpu_baseline(name, n, budget_s):
@@ -143,10 +140,6 @@ class HandBench:
     def resets(self):
         return int(self.task._reset_out["count"].item())
 
-    def stats(self, out):
-        t = self.task
-        out[0], out[1], out[2] = t.rew_buf.sum(), t.reset_buf.sum(), (t.progress_buf * t.reset_buf).sum()
-        out[3] = t.successes.sum()
 
     @staticmethod
     def cpu_baseline(name, n, budget_s):
@@ -214,10 +207,6 @@ class AnymalBench:
     def resets(self):
         return int(self.task._reset_out["count"].item())
 
-    def stats(self, out):
-        t = self.task
-        out[0], out[1], out[2] = t.rew_buf.sum(), t.reset_buf.sum(), (t.progress_buf * t.reset_buf).sum()
-        out[3] = t.terrain_levels.sum()
 
     @staticmethod
     def cpu_baseline(name, n, budget_s):
@@ -305,9 +294,10 @@ def main() -> None:
         torch.cuda.set_device(0)
     dev = f"cuda:{local_rank if world > 1 else 0}"
 
+    from omniisaacgymenvs_amd.utils import distributed as od
+
     n = args.envs or DEFAULT_ENVS[args.task]
-    bench = ADAPTERS[args.task](args.task, n, dev, 1234 + rank)
-    stats = torch.zeros(8, dtype=torch.float32, device=dev)
+    bench = ADAPTERS[args.task](args.task, n, dev, od.rank_seed(1234, rank))
 
     ev_pairs = []
     after = getattr(bench, "after_post", lambda: None)
@@ -332,10 +322,10 @@ def main() -> None:
     t0 = time.perf_counter()
     for _ in range(args.steps):
         timed_step()
-    if dist is not None:
-        # episode statistics: [sum reward, n done, sum episode length of done envs, successes / terrain level] -- 32 bytes
-        bench.stats(stats)
-        dist.all_reduce(stats)
+    # episode statistics [sum reward, n done, sum episode length of done envs, successes, n envs]: the path's only
+    # cross-rank exchange, one 40-byte all-reduce over RCCL (utils/distributed.py)
+    t = bench.task
+    job_stats = od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -359,6 +349,7 @@ def main() -> None:
         cfg = {"workload": bench.workload, "envs_per_gpu": n, "resets_per_step": bench.resets(),
                "step": "pre_physics_step + post_physics_step via RLTask API (physics delegated)"}
         cfg.update(bench.extra_cfg)
+        cfg["episode_stats"] = {k: round(v, 4) for k, v in job_stats.items()}
         out = {
             "metric": "fused obs+reward+reset env-steps/s",
             "value": world * n * args.steps / elapsed,
