@@ -18,6 +18,7 @@ Prints ONE JSON line (rank 0).
 from __future__ import annotations
 
 import argparse
+import contextlib
 import copy
 import json
 import os
@@ -297,7 +298,8 @@ def main() -> None:
     from omniisaacgymenvs_amd.utils import distributed as od
 
     n = args.envs or DEFAULT_ENVS[args.task]
-    bench = ADAPTERS[args.task](args.task, n, dev, od.rank_seed(1234, rank))
+    with contextlib.redirect_stdout(sys.stderr):  # the task constructors print like the reference's; stdout carries ONE JSON line
+        bench = ADAPTERS[args.task](args.task, n, dev, od.rank_seed(1234, rank))
 
     ev_pairs = []
     after = getattr(bench, "after_post", lambda: None)

@@ -54,19 +54,22 @@ __global__ __launch_bounds__(GROUP) void dr_noise_count_kernel(const oige_noise_
 __device__ __forceinline__ void noise_samples(const oige_noise_term& t, const u4 x, float out[4]) {
   const float u[4] = {u01(x.x), u01(x.y), u01(x.z), u01(x.w)};
   if (t.distribution == OIGE_NOISE_GAUSSIAN) {  // Box-Muller, two pairs; 1 - u in (0, 1]
+    // Hardware transcendentals (v_log_f32 = log2, v_sin/v_cos_f32 take REVOLUTIONS, so the angle 2*pi*u needs no
+    // multiply or range reduction): the precise libm calls made this kernel VALU-bound at 1.6 TB/s.  These
+    // samples are distribution-parity only (torch's RNG cannot be replayed in-kernel); they agree with the numpy
+    // restatement (oracle/dr_noise_oracle.py) to ~1e-6 relative.
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const float r = __builtin_sqrtf(-2.0f * logf(1.0f - u[2 * h]));
-      const float th = OIGE_TWO_PI_F * u[2 * h + 1];
-      out[2 * h] = (r * cosf(th)) * t.p1 + t.p0;
-      out[2 * h + 1] = (r * sinf(th)) * t.p1 + t.p0;
+      const float r = __builtin_amdgcn_sqrtf((-2.0f * 0.69314718055994530942f) * __builtin_amdgcn_logf(1.0f - u[2 * h]));
+      out[2 * h] = (r * __builtin_amdgcn_cosf(u[2 * h + 1])) * t.p1 + t.p0;
+      out[2 * h + 1] = (r * __builtin_amdgcn_sinf(u[2 * h + 1])) * t.p1 + t.p0;
     }
   } else if (t.distribution == OIGE_NOISE_UNIFORM) {  // (hi - lo) * rand + lo  (:353-355)
 #pragma unroll
     for (int k = 0; k < 4; ++k) out[k] = t.p1 * u[k] + t.p0;
   } else {  // exp((log hi - log lo) * rand + log lo)  (:357-361)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = expf(t.p1 * u[k] + t.p0);
+    for (int k = 0; k < 4; ++k) out[k] = __expf(t.p1 * u[k] + t.p0);
   }
 }
 

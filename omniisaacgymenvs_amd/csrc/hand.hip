@@ -422,69 +422,188 @@ __device__ __forceinline__ void hand_reset_env(const HandPre& a, int64_t i, int6
   a.r.env_ids[k] = i;
 }
 
-// action application for env i (:331-358), after any reset of the same env
-__device__ __forceinline__ void hand_apply_actions(const HandPre& a, int64_t i) {
+// reset_idx (:397-441) WITHOUT its (.,24) DOF rows: goal re-draw, object pose rows, flags.  The DOF rows and
+// the prev/cur targets of a reset env are produced by the elementwise pass of hand_pre_kernel.
+__device__ __forceinline__ void hand_reset_env_head(const HandPre& a, int64_t i, int64_t k) {
   const oige_hand_params& p = a.p;
-  float act[HA];
-  const float4* ar = reinterpret_cast<const float4*>(a.actions_in + i * HA);
+  float u[8];
+  hand_draw<8>(a.r, i, 1u, u);                                                                     // draws 0..4 of the (n,53) table
+  hand_reset_goal(a, i, k, nullptr, 2u, a.r.r_goal_world_pos_out, a.r.r_goal_rot_out);             // :401
+  const float* oi = a.r.object_init_pos + i * 3;
+  const float* ep = a.r.env_pos + i * 3;
 #pragma unroll
-  for (int k = 0; k < HA / 4; ++k) {
-    const float4 v = ar[k];
-    act[4 * k] = v.x; act[4 * k + 1] = v.y; act[4 * k + 2] = v.z; act[4 * k + 3] = v.w;
-  }
-  if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
+  for (int c = 0; c < 3; ++c) a.r.object_pos_out[k * 3 + c] = (oi[c] + p.reset_position_noise * u[c]) + ep[c];  // :404-406
+  const q4 orot = randomize_rotation(u[3], u[4]);                                                       // :408-410
+  *reinterpret_cast<float4*>(a.r.object_rot_out + k * 4) = make_float4(orot.w, orot.x, orot.y, orot.z);
 #pragma unroll
-    for (int k = 0; k < HA; ++k) act[k] = clamp_sym(act[k], p.clip_actions);
-  }
-  if (a.actions_out) {
-    float4* ao = reinterpret_cast<float4*>(a.actions_out + i * HA);
-#pragma unroll
-    for (int k = 0; k < HA / 4; ++k) ao[k] = make_float4(act[4 * k], act[4 * k + 1], act[4 * k + 2], act[4 * k + 3]);
-  }
-  float out[HA];
-  const float one_minus = p.one_minus_act_moving_average;
-  const float speed_dt = p.dof_speed_scale_dt;
-#pragma unroll
-  for (int k = 0; k < HA; ++k) {
-    const int j = p.actuated_dof_indices[k];
-    const float lo = p.dof_lower[j], hi = p.dof_upper[j];
-    const float prev = a.b.prev_targets[i * HD + j];
-    float c;
-    if (p.use_relative_control) {
-      c = tensor_clamp(prev + speed_dt * act[k], lo, hi);  // :334-341
-    } else {
-      c = scale(act[k], lo, hi);                            // :343-347
-      c = p.act_moving_average * c + one_minus * prev;     // :348-351
-      c = tensor_clamp(c, lo, hi);                          // :352-356
-    }
-    a.b.cur_targets[i * HD + j] = c;
-    a.b.prev_targets[i * HD + j] = c;  // :358
-    out[k] = c;
-  }
-  float4* to = reinterpret_cast<float4*>(a.targets_out + i * HA);
-#pragma unroll
-  for (int k = 0; k < HA / 4; ++k) to[k] = make_float4(out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]);
+  for (int c = 0; c < 6; ++c) a.r.object_vel_out[k * 6 + c] = 0.0f;  // :412-413
+  a.b.progress_buf[i] = 0;  // :439-441
+  a.b.reset_buf[i] = 0;
+  a.b.successes[i] = 0.0f;
+  a.r.env_ids[k] = i;
 }
 
+// draws idx0 .. idx0+3 of env i's U(-1,1) table on `stream`, idx0 = 4m + 1: words 1..3 of block m, word 0 of block m+1
+__device__ __forceinline__ void hand_draw4_at(const oige_hand_reset_io& r, int64_t i, uint32_t stream, int idx0, float (&out)[4]) {
+  const uint32_t m = (uint32_t)(idx0 >> 2);
+  const u4 c0{(uint32_t)i, m | (stream << 16), (uint32_t)r.step, (uint32_t)(r.step >> 32)};
+  const u4 c1{(uint32_t)i, (m + 1u) | (stream << 16), (uint32_t)r.step, (uint32_t)(r.step >> 32)};
+  const u4 x0 = philox4x32_10(c0, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+  const u4 x1 = philox4x32_10(c1, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+  out[0] = um11(x0.y); out[1] = um11(x0.z); out[2] = um11(x0.w); out[3] = um11(x1.x);
+}
+
+// pre_physics_step (:314-362) for one group of 256 envs, in four phases:
+//   1. compaction ranks of reset_goal_buf / reset_buf; the group's actions (one contiguous 256x20 run) are read
+//      lane-linear, clamped, cloned to actions_out and staged in LDS;
+//   2. the flagged envs run reset_target_pose / reset_idx on DENSE lanes (thread j = j-th flagged env of the group);
+//   3. one lane-linear pass over the group's contiguous 256x24 prev/cur target rows: reset rows take their
+//      re-drawn DOF positions (also written as compacted dof_pos_out / dof_vel_out rows), then every actuated
+//      element gets scale -> EMA -> clamp (or the relative-control update); results land in the LDS action tile;
+//   4. the LDS tile streams out as targets_out.
+// Every global access of phases 1, 3 and 4 is a 16-byte lane-linear one (the first version wrote prev/cur/targets with
+// per-env strided dword stores: 4x the algorithmic write traffic, 460 us at 1 M envs).
 __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
   __shared__ int lds_a[GROUP_TILES], lds_b[GROUP_TILES];
+  __shared__ int s_list_r[GROUP], s_list_g[GROUP], s_rank[GROUP];
+  __shared__ int s_inv[HD];
+  __shared__ __align__(16) float s_act[GROUP * HA];
+  const oige_hand_params& p = a.p;
+  const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
-  const int64_t env = g * GROUP + threadIdx.x;
+  const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
   const int32_t* off_r = a.b.reset_workspace + G * GROUP_TILES;
   const int32_t* off_g = a.b.goal_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
   const bool f_env = live && a.b.reset_buf[env] != 0;
   const bool f_goal = live && a.b.reset_goal_buf[env] != 0;
-  const int64_t kg = group_rank(f_goal, off_g, g, lds_b);
+  if (tid < HD) s_inv[tid] = -1;
+  const int64_t kg = group_rank(f_goal, off_g, g, lds_b);  // (barrier inside)
   const int64_t kr = group_rank(f_env, off_r, g, lds_a);
-  if (f_goal) {
-    hand_reset_goal(a, env, kg, a.r.u_goal, 0u, a.r.goal_world_pos_out, a.r.goal_rot_out);  // :324-327
-    a.r.goal_ids[kg] = env;
+  const int32_t k0g = off_g[g], k0r = off_r[g];
+  const int cntg = off_g[g + 1] - k0g, cntr = off_r[g + 1] - k0r;
+  if (f_goal) s_list_g[(int)(kg - k0g)] = tid;
+  if (f_env) s_list_r[(int)(kr - k0r)] = tid;
+  s_rank[tid] = f_env ? (int)(kr - k0r) : -1;
+  if (tid < HA) s_inv[p.actuated_dof_indices[tid]] = tid;
+
+  // ---- 1: actions -> (clamp) -> actions_out, LDS
+  const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
+  {
+    const int64_t base = g * GROUP * HA;
+    const int nf4 = (int)(envs_here * HA / 4);  // HA % 4 == 0
+#pragma unroll
+    for (int it = 0; it < HA / 4; ++it) {
+      const int f = it * GROUP + tid;
+      if (f < nf4) {
+        float4 v = *reinterpret_cast<const float4*>(a.actions_in + base + 4 * f);
+        if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
+          v.x = clamp_sym(v.x, p.clip_actions); v.y = clamp_sym(v.y, p.clip_actions);
+          v.z = clamp_sym(v.z, p.clip_actions); v.w = clamp_sym(v.w, p.clip_actions);
+        }
+        if (a.actions_out) *reinterpret_cast<float4*>(a.actions_out + base + 4 * f) = v;
+        *reinterpret_cast<float4*>(s_act + 4 * f) = v;
+      }
+    }
   }
-  if (f_env) hand_reset_env(a, env, kr);  // :328-329
-  if (live) hand_apply_actions(a, env);
-  if (g == 0 && threadIdx.x == 0) {
+  __syncthreads();
+
+  // ---- 2: dense resets; goal-only ids first (:324-327), then reset_idx (:328-329), whose nested reset_target_pose
+  // must win on envs that are in both lists
+  if (tid < cntg) {
+    const int64_t i = g * GROUP + s_list_g[tid];
+    hand_reset_goal(a, i, (int64_t)k0g + tid, nullptr, 0u, a.r.goal_world_pos_out, a.r.goal_rot_out);
+    a.r.goal_ids[k0g + tid] = i;
+  }
+  __syncthreads();
+  if (tid < cntr) hand_reset_env_head(a, g * GROUP + s_list_r[tid], (int64_t)k0r + tid);
+
+  // ---- 3: prev/cur targets, lane-linear over the group's 256 x 24 floats
+  const float one_minus = p.one_minus_act_moving_average;
+  const float speed_dt = p.dof_speed_scale_dt;
+  {
+    const int64_t base = g * GROUP * HD;
+    const int nf4 = (int)(envs_here * HD / 4);  // HD % 4 == 0
+#pragma unroll
+    for (int it = 0; it < HD / 4; ++it) {
+      const int f = it * GROUP + tid;
+      if (f >= nf4) continue;
+      const int e = 4 * f;
+      const int il = e / HD, j0 = e - il * HD;
+      const int64_t i = g * GROUP + il;
+      const int lr = s_rank[il];
+      int kk[4];
+      bool all_act = true;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        kk[q] = s_inv[j0 + q];
+        all_act = all_act && kk[q] >= 0;
+      }
+      float prev[4], cur[4];
+      if (lr >= 0) {  // reset row: re-drawn DOF state (:415-436)
+        float up[4], uv[4] = {0.f, 0.f, 0.f, 0.f};
+        hand_draw4_at(a.r, i, 1u, 5 + j0, up);
+        if (p.reset_dof_vel_noise != 0.0f) hand_draw4_at(a.r, i, 1u, 5 + HD + j0, uv);
+        float vel[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int j = j0 + q;
+          const float delta_max = p.dof_upper[j] - p.dof_default_pos[j];
+          const float delta_min = p.dof_lower[j] - p.dof_default_pos[j];
+          const float rand_delta = delta_min + ((delta_max - delta_min) * 0.5f) * (up[q] + 1.0f);  // :419
+          prev[q] = p.dof_default_pos[j] + p.reset_dof_pos_noise * rand_delta;                      // :421
+          vel[q] = p.dof_default_vel[j] + p.reset_dof_vel_noise * uv[q];                            // :426-429
+          cur[q] = prev[q];                                                                          // :431-432
+        }
+        const int64_t row = ((int64_t)k0r + lr) * HD + j0;
+        *reinterpret_cast<float4*>(a.r.dof_pos_out + row) = make_float4(prev[0], prev[1], prev[2], prev[3]);
+        *reinterpret_cast<float4*>(a.r.dof_vel_out + row) = make_float4(vel[0], vel[1], vel[2], vel[3]);
+      } else {
+        const float4 t = *reinterpret_cast<const float4*>(a.b.prev_targets + base + e);
+        prev[0] = t.x; prev[1] = t.y; prev[2] = t.z; prev[3] = t.w;
+        if (!all_act) {  // an unactuated DOF keeps its current target
+          const float4 c4 = *reinterpret_cast<const float4*>(a.b.cur_targets + base + e);
+          cur[0] = c4.x; cur[1] = c4.y; cur[2] = c4.z; cur[3] = c4.w;
+        } else {
+          cur[0] = cur[1] = cur[2] = cur[3] = 0.0f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (kk[q] < 0) continue;
+        const int j = j0 + q;
+        const float lo = p.dof_lower[j], hi = p.dof_upper[j];
+        const float act = s_act[il * HA + kk[q]];
+        float c;
+        if (p.use_relative_control) {
+          c = tensor_clamp(prev[q] + speed_dt * act, lo, hi);  // :334-341
+        } else {
+          c = scale(act, lo, hi);                                // :343-347
+          c = p.act_moving_average * c + one_minus * prev[q];   // :348-351
+          c = tensor_clamp(c, lo, hi);                           // :352-356
+        }
+        cur[q] = c;
+        prev[q] = c;  // :358
+        s_act[il * HA + kk[q]] = c;  // the action slot becomes the target slot (same thread reads and writes it)
+      }
+      *reinterpret_cast<float4*>(a.b.cur_targets + base + e) = make_float4(cur[0], cur[1], cur[2], cur[3]);
+      *reinterpret_cast<float4*>(a.b.prev_targets + base + e) = make_float4(prev[0], prev[1], prev[2], prev[3]);
+    }
+  }
+  __syncthreads();
+
+  // ---- 4: targets_out = cur_targets[:, actuated] (:360-362)
+  {
+    const int64_t base = g * GROUP * HA;
+    const int nf4 = (int)(envs_here * HA / 4);
+#pragma unroll
+    for (int it = 0; it < HA / 4; ++it) {
+      const int f = it * GROUP + tid;
+      if (f < nf4) *reinterpret_cast<float4*>(a.targets_out + base + 4 * f) = *reinterpret_cast<const float4*>(s_act + 4 * f);
+    }
+  }
+  if (g == 0 && tid == 0) {
     *a.r.count = (int64_t)off_r[G];
     *a.r.goal_count = (int64_t)off_g[G];
   }
@@ -635,6 +754,8 @@ int oige_hand_pre_physics(const oige_hand_params* params, const float* actions_i
                "hand_pre_physics: null reset output pointer");
   OIGE_REQUIRE(aligned16(r.goal_rot_out) && aligned16(r.r_goal_rot_out) && aligned16(r.object_rot_out),
                "hand_pre_physics: (n,4) outputs must be 16-byte aligned");
+  OIGE_REQUIRE(aligned16(a.b.prev_targets) && aligned16(a.b.cur_targets) && aligned16(r.dof_pos_out) && aligned16(r.dof_vel_out),
+               "hand_pre_physics: prev/cur targets and dof row outputs must be 16-byte aligned");
   OIGE_REQUIRE(!r.u_goal && !r.u_reset && !r.u_reset_goal,
                "hand_pre_physics: pre-drawn noise goes through oige_hand_reset_idx / oige_hand_reset_target_pose");
   a.actions_in = actions_in;

@@ -300,14 +300,26 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
         if (4 * blk + q < 2 * D) u[4 * blk + q] = u01(w[q]);
     }
   }
+  float qp[D], qv[D];
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     // torch_rand_float(lo, hi): (hi - lo) * u + lo, with hi - lo folded in double first (:137,:139)
     const float dp = 0.4f * u[j] + (-0.2f);
-    const float dv = 0.2f * u[D + j] + (-0.1f);
-    r.dof_pos_out[k * D + j] =
-        tensor_clamp(r.initial_dof_pos[i * D + j] + dp, p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :138
-    r.dof_vel_out[k * D + j] = dv;
+    qp[j] = tensor_clamp(r.initial_dof_pos[i * D + j] + dp, p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :138
+    qv[j] = 0.2f * u[D + j] + (-0.1f);
+  }
+  if (D % 4 == 0 && aligned16(r.dof_pos_out) && aligned16(r.dof_vel_out)) {  // whole rows as 16-byte stores
+#pragma unroll
+    for (int c = 0; c < D / 4; ++c) {
+      reinterpret_cast<float4*>(r.dof_pos_out + k * D)[c] = make_float4(qp[4 * c], qp[4 * c + 1], qp[4 * c + 2], qp[4 * c + 3]);
+      reinterpret_cast<float4*>(r.dof_vel_out + k * D)[c] = make_float4(qv[4 * c], qv[4 * c + 1], qv[4 * c + 2], qv[4 * c + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      r.dof_pos_out[k * D + j] = qp[j];
+      r.dof_vel_out[k * D + j] = qv[j];
+    }
   }
   const float* ip = r.initial_root_pos + i * 3;
   const float4 iq = *reinterpret_cast<const float4*>(r.initial_root_rot + i * 4);
@@ -329,6 +341,7 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
 template <int D>
 __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) {
   __shared__ int lds4[GROUP_TILES];
+  __shared__ int s_list[GROUP];
   const int64_t g = blockIdx.x;
   const int64_t env = g * GROUP + threadIdx.x;
   const int64_t G = num_groups(a.n);
@@ -375,10 +388,17 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
     }
   }
 
-  // compaction rank + reset of the flagged envs (:121-123)
+  // compaction rank + reset of the flagged envs (:121-123).  The flagged envs of the group are first packed
+  // into LDS so that the reset runs on DENSE lanes (thread j takes the group's j-th flagged env): with a few
+  // flagged lanes per wave the divergent version spent 4 waves' worth of issue slots on ~10 % of the lanes, and
+  // consecutive lanes now write consecutive compacted rows.
   const bool flagged = env < a.n && a.b.reset_buf[env] != 0;
   const int64_t k = group_rank(flagged, group_offsets, g, lds4);
-  if (flagged) reset_env<D>(a.p, a.b, a.r, env, k);
+  const int32_t k0 = group_offsets[g];
+  const int cnt = group_offsets[g + 1] - k0;
+  if (flagged) s_list[(int)(k - k0)] = (int)threadIdx.x;
+  __syncthreads();
+  if ((int)threadIdx.x < cnt) reset_env<D>(a.p, a.b, a.r, g * GROUP + s_list[threadIdx.x], (int64_t)k0 + threadIdx.x);
   if (g == 0 && threadIdx.x == 0) *a.r.count = (int64_t)group_offsets[G];
 }
 

@@ -27,7 +27,7 @@ inline int fail(int code, const char* fmt, ...) {
   return code;
 }
 
-inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+__host__ __device__ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 inline int check_launch(const char* what) {
   hipError_t e = hipGetLastError();
