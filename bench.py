@@ -250,6 +250,31 @@ DEFAULT_ENVS = {"Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "Any
 CPU_ENVS = {"Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
+def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:
+    """Calibration: liboige's plain streaming copy (read + write) at this kernel's footprint, over 1 and 12 lock-step
+    sub-arrays (a task kernel walks about a dozen separate (N,k) tensors at once) -- the practical ceilings to read the
+    roofline fraction against.  GB/s of read+write traffic, HIP events on the launch stream."""
+    from omniisaacgymenvs_amd import _lib
+
+    lib = _lib.load()
+    half = max((footprint_bytes // 2) // (16 * 12) * (16 * 12), 16 * 12)
+    src = torch.empty(half, dtype=torch.uint8, device=dev).random_(0, 255)
+    dst = torch.empty_like(src)
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for streams in (1, 12):
+        for _ in range(5):
+            _lib.check(lib.oige_stream_copy(src.data_ptr(), dst.data_ptr(), half, streams, st), "oige_stream_copy")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50):
+            lib.oige_stream_copy(src.data_ptr(), dst.data_ptr(), half, streams, st)
+        e1.record()
+        torch.cuda.synchronize()
+        out[f"streams_{streams}"] = 2 * half / (e0.elapsed_time(e1) / 50 * 1e-3) / 1e9
+    return out
+
+
 def cpu_baseline(task_name: str, n: int, budget_s: float = 12.0):
     """The oracle (CPU torch restatement of the reference) timed on the host cores: bounded sample."""
     step = ADAPTERS[task_name].cpu_baseline(task_name, n, budget_s)
@@ -339,6 +364,7 @@ def main() -> None:
         elapsed = float(t.item())
 
     post_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
+    copy_gbs = measured_copy_gbs(dev, bench.post_bytes * n) if rank == 0 else None
     achieved = bench.post_bytes * n / (post_ms * 1e-3) / 1e9
     traffic = None
     if args.traffic_json and os.path.exists(args.traffic_json):
@@ -370,6 +396,8 @@ def main() -> None:
                 "bound": "hbm", "kernel": bench.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_env": bench.post_bytes, "avg_kernel_ms": post_ms,
+                "measured_copy_gbs": copy_gbs,
+                "frac_of_measured_copy_12_streams": achieved / copy_gbs["streams_12"],
             },
         }
         if not args.no_cpu_baseline and world == 1:

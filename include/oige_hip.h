@@ -39,6 +39,12 @@ typedef void* oige_stream_t; /* hipStream_t */
 const char* oige_last_error(void);
 int oige_version(void);
 
+/* Measurement aid, no counterpart in the reference: a 16-byte-per-lane streaming copy of `bytes` from src to dst.
+ * `streams` (1..64; bytes % (16*streams) == 0) splits both buffers into that many sub-arrays walked in lockstep, the way
+ * a task kernel walks its separate (N,k) tensors.  bench.py times it to report the chip's practical read+write stream
+ * rate beside the 8 TB/s spec peak.                                                                    */
+int oige_stream_copy(const void* src, void* dst, int64_t bytes, int32_t streams, oige_stream_t stream);
+
 /* ------------------------------------------------------------------ compaction
  * reset_env_ids = reset_buf.nonzero().squeeze(-1): ascending int64 ids, without the host
  * sync of len() (tasks/shared/locomotion.py:121-122, cartpole.py:112-113,

@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboige_hip.so")
+LIB_PATH = os.environ.get("OIGE_LIB") or os.path.join(_HERE, "liboige_hip.so")  # OIGE_LIB: kernel-variant experiments
 
 OIGE_MAX_DOF = 32
 TILE_ENVS = 64
@@ -201,6 +201,7 @@ SIGNATURES = {
                                       C.c_int64, _P]),
     "oige_hand_reset_target_pose": (C.c_int, [C.POINTER(HandParams), C.POINTER(HandBuffers), C.POINTER(HandResetIO),
                                               C.c_int64, C.c_int64, _P]),
+    "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "oige_dr_noise_count": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_dr_noise_apply": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_anymal_torques": (C.c_int, [C.POINTER(AnymalParams), _P, _P, _P, _P, C.c_int64, _P]),

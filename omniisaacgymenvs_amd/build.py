@@ -43,6 +43,18 @@ def is_stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_variant(name: str, defines, verbose: bool = True) -> str:
+    """Experiment builds: omniisaacgymenvs_amd/variants/liboige_<name>.so with extra -D flags (select with OIGE_LIB)."""
+    out_dir = os.path.join(HERE, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"liboige_{name}.so")
+    cmd = [_hipcc()] + FLAGS + [f"-D{d}" for d in defines] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", out]
+    if verbose:
+        print("[oige build]", name, defines, flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not is_stale():
         return LIB

@@ -83,26 +83,32 @@ __device__ __forceinline__ float reward_of(const oige_locomotion_params& p, floa
   return obs0 < p.termination_height ? p.death_cost : total;
 }
 
+#ifndef OIGE_POST_NT
+#define OIGE_POST_NT 64  // threads per 64-env tile in the post kernel (64 = one wave per tile)
+#endif
+constexpr int PNT = OIGE_POST_NT;
+
 template <int D, int S, int LIMIT, bool FULL>
 __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__ tile, int64_t t, int nv) {
   constexpr int OBS = 12 + 3 * D + 6 * S;
   constexpr int C_DPOS = 12, C_DVEL = 12 + D, C_SENS = 12 + 2 * D, C_ACT = 12 + 2 * D + 6 * S;
   const oige_locomotion_params& p = a.p;
   const int lane = lane_id();
+  const bool env_wave = PNT == WAVE || threadIdx.x < WAVE;  // the wave that does the one-env-per-lane part
   const int64_t env0 = t * TILE;
   const int64_t env = env0 + lane;
-  const bool live = FULL || lane < nv;
+  const bool live = env_wave && (FULL || lane < nv);
   const bool do_progress = a.stages & OIGE_STAGE_PROGRESS;
   const bool do_metrics = a.stages & OIGE_STAGE_METRICS;
   const bool do_done = a.stages & OIGE_STAGE_DONE;
 
   // ---- A: all loads in flight
-  Chunk<D> c_dpos, c_dvel, c_act;
-  Chunk<6 * S> c_sens;
-  load_chunk<D, FULL>(c_dpos, a.s.dof_pos + env0 * D, nv * D);
-  load_chunk<D, FULL>(c_dvel, a.s.dof_vel + env0 * D, nv * D);
-  load_chunk<6 * S, FULL>(c_sens, a.s.sensor_force_torques + env0 * (6 * S), nv * 6 * S);
-  load_chunk<D, FULL>(c_act, a.b.actions + env0 * D, nv * D);
+  Chunk<D, PNT> c_dpos, c_dvel, c_act;
+  Chunk<6 * S, PNT> c_sens;
+  load_chunk<D, FULL, PNT>(c_dpos, a.s.dof_pos + env0 * D, nv * D);
+  load_chunk<D, FULL, PNT>(c_dvel, a.s.dof_vel + env0 * D, nv * D);
+  load_chunk<6 * S, FULL, PNT>(c_sens, a.s.sensor_force_torques + env0 * (6 * S), nv * 6 * S);
+  load_chunk<D, FULL, PNT>(c_act, a.b.actions + env0 * D, nv * D);
 
   f3 pos{0.f, 0.f, 1.f}, lin{0.f, 0.f, 0.f}, ang{0.f, 0.f, 0.f};
   q4 rot{1.f, 0.f, 0.f, 0.f};
@@ -123,12 +129,14 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
   }
 
   // ---- B: pass-through columns into the obs tile
-  scatter_chunk<D, OBS, C_DPOS, false>(c_dpos, tile, 1.0f);  // raw; unscaled per env in C
-  scatter_chunk<D, OBS, C_DVEL, true>(c_dvel, tile, p.dof_vel_scale);
-  scatter_chunk<6 * S, OBS, C_SENS, true>(c_sens, tile, p.contact_force_scale);
-  scatter_chunk<D, OBS, C_ACT, false>(c_act, tile, 1.0f);
+  scatter_chunk<D, OBS, C_DPOS, false, PNT>(c_dpos, tile, 1.0f);  // raw; unscaled per env in C
+  scatter_chunk<D, OBS, C_DVEL, true, PNT>(c_dvel, tile, p.dof_vel_scale);
+  scatter_chunk<6 * S, OBS, C_SENS, true, PNT>(c_sens, tile, p.contact_force_scale);
+  scatter_chunk<D, OBS, C_ACT, false, PNT>(c_act, tile, 1.0f);
 
-  // ---- C: per-env math (locomotion.py:249-263)
+  // ---- C: per-env math (locomotion.py:249-263), one env per lane of the tile's first wave
+  if (PNT != WAVE) __syncthreads();  // B's cross-wave LDS writes visible
+  if (env_wave) {
   if (do_progress) progress += 1;  // rl_task.py:289, before is_done reads it
 
   const f3 target{p.target[0], p.target[1], p.target[2]};
@@ -163,7 +171,7 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
   head[10] = up_proj;
   head[11] = heading_proj;
 
-  __syncthreads();  // B's cross-lane LDS writes visible (single-wave workgroup: a wave-local fence)
+  if (PNT == WAVE) __syncthreads();  // B's cross-lane LDS writes visible (single-wave workgroup: a wave-local fence)
 
   float* row = tile + lane * OBS;
   float dps[D], dvs[D], act[D];
@@ -207,15 +215,16 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
     const unsigned long long m = __ballot(live && r != 0);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
   }
+  }  // env_wave
 
   __syncthreads();  // C's row writes visible to the lane-linear readout
 
   // ---- D: finished obs tile -> HBM, one contiguous run
-  store_tile<OBS, FULL>(tile, a.b.obs_buf + env0 * OBS, nv * OBS);
+  store_tile<OBS, FULL, PNT>(tile, a.b.obs_buf + env0 * OBS, nv * OBS);
 }
 
 template <int D, int S, int LIMIT>
-__global__ __launch_bounds__(WAVE) void locomotion_post_kernel(const LocoPost a) {
+__global__ __launch_bounds__(PNT) void locomotion_post_kernel(const LocoPost a) {
   constexpr int OBS = 12 + 3 * D + 6 * S;
   __shared__ __align__(16) float tile[TILE * OBS];
   const int64_t t = blockIdx.x;
@@ -428,9 +437,9 @@ static int launch_post(const LocoPost& a, hipStream_t s) {
   if (T == 0) return OIGE_OK;
   if (a.stages & OIGE_STAGE_OBS) {
     if (a.p.limit_cost_kind == 0)
-      hipLaunchKernelGGL((locomotion_post_kernel<D, S, 0>), dim3((unsigned)T), dim3(WAVE), 0, s, a);
+      hipLaunchKernelGGL((locomotion_post_kernel<D, S, 0>), dim3((unsigned)T), dim3(PNT), 0, s, a);
     else
-      hipLaunchKernelGGL((locomotion_post_kernel<D, S, 1>), dim3((unsigned)T), dim3(WAVE), 0, s, a);
+      hipLaunchKernelGGL((locomotion_post_kernel<D, S, 1>), dim3((unsigned)T), dim3(PNT), 0, s, a);
     return check_launch("locomotion_post_kernel");
   }
   const unsigned blocks = (unsigned)((a.n + 255) / 256);

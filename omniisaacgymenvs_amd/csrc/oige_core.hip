@@ -79,6 +79,18 @@ __global__ __launch_bounds__(GROUP) void emit_ids_kernel(const int64_t* __restri
   if (g == 0 && threadIdx.x == 0) *count = (int64_t)group_offsets[n_groups];
 }
 
+// Calibration only: a streaming copy (16 B per lane, fully coalesced, read n bytes + write n bytes), the practical
+// ceiling of a 50/50 read/write HBM stream on this chip; bench.py reports it beside the 8 TB/s spec peak.
+// `streams` splits the buffers into that many equal sub-arrays and every thread copies the same index of each, the
+// way one task kernel walks a dozen separate (N,k) tensors at once.
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4,
+                                                          int streams) {
+  const int64_t per = n4 / streams;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= per) return;
+  for (int s = 0; s < streams; ++s) dst[s * per + i] = src[s * per + i];
+}
+
 int launch_count_flags(const int64_t* flags, int64_t n, int32_t* ws, hipStream_t stream) {
   const int64_t G = num_groups(n);
   if (G == 0) return OIGE_OK;
@@ -102,6 +114,18 @@ const char* oige_last_error(void) { return error_buffer(); }
 int oige_version(void) { return OIGE_ABI_VERSION; }
 int64_t oige_num_tiles(int64_t n) { return n < 0 ? 0 : num_tiles(n); }
 int64_t oige_workspace_ints(int64_t n) { return n < 0 ? 0 : workspace_ints(n); }
+
+int oige_stream_copy(const void* src, void* dst, int64_t bytes, int32_t streams, oige_stream_t stream) {
+  OIGE_REQUIRE(src && dst && bytes >= 0 && aligned16(src) && aligned16(dst), "stream_copy: bad arguments");
+  OIGE_REQUIRE(streams >= 1 && streams <= 64 && bytes % (16 * (int64_t)streams) == 0, "stream_copy: bytes must be a multiple of 16 * streams");
+  const int64_t n4 = bytes / 16;
+  if (n4 == 0) return OIGE_OK;
+  const int64_t g = (n4 / streams + 255) / 256;
+  OIGE_REQUIRE(g < ((int64_t)1 << 31), "stream_copy: too large");
+  hipLaunchKernelGGL(stream_copy_kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n4, (int)streams);
+  return check_launch("stream_copy_kernel");
+}
 
 int oige_count_flags_i64(const int64_t* flags, int64_t n, int32_t* workspace, oige_stream_t stream) {
   OIGE_REQUIRE(n >= 0 && n < (int64_t)1 << 31, "count_flags: num_envs %lld out of range", (long long)n);

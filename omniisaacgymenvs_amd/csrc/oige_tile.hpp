@@ -9,26 +9,27 @@
 
 namespace oige {
 
-template <int K>
+// NT = threads that share the tile (64: one wave; 128 / 256: the waves of one workgroup split every run)
+template <int K, int NT = WAVE>
 struct Chunk {
   static constexpr int NF4 = (TILE * K) / 4;          // float4 pieces in a full tile (TILE*K % 4 == 0)
-  static constexpr int ITERS = (NF4 + WAVE - 1) / WAVE;  // per-lane float4 count
-  static constexpr bool EXACT = (NF4 % WAVE) == 0;       // no lane masking needed on a full tile
+  static constexpr int ITERS = (NF4 + NT - 1) / NT;   // per-thread float4 count
+  static constexpr bool EXACT = (NF4 % NT) == 0;      // no thread masking needed on a full tile
   float4 v[ITERS];
 };
 
 // Load the tile's contiguous run.  `src` points at the tile's first float and is 16-byte
 // aligned (tile start = 64*K floats = multiple of 256 B past a 16-byte aligned base).
 // `valid` = number of floats that exist (64*K on a full tile).
-template <int K, bool FULL>
-__device__ __forceinline__ void load_chunk(Chunk<K>& c, const float* __restrict__ src, int valid) {
-  const int lane = lane_id();
+template <int K, bool FULL, int NT = WAVE>
+__device__ __forceinline__ void load_chunk(Chunk<K, NT>& c, const float* __restrict__ src, int valid) {
+  const int lane = NT == WAVE ? lane_id() : (int)threadIdx.x;
 #pragma unroll
-  for (int it = 0; it < Chunk<K>::ITERS; ++it) {
-    const int f = it * WAVE + lane;
+  for (int it = 0; it < Chunk<K, NT>::ITERS; ++it) {
+    const int f = it * NT + lane;
     const int e = 4 * f;
     if (FULL) {
-      if (Chunk<K>::EXACT || f < Chunk<K>::NF4)
+      if (Chunk<K, NT>::EXACT || f < Chunk<K, NT>::NF4)
         c.v[it] = *reinterpret_cast<const float4*>(src + e);
       else
         c.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -48,13 +49,13 @@ __device__ __forceinline__ void load_chunk(Chunk<K>& c, const float* __restrict_
 
 // Scatter a loaded run into the (64 x ROW) LDS tile at column COL0, multiplying by `s`
 // (MUL=false: plain copy).  Element e of the run belongs to env e / K, column e % K.
-template <int K, int ROW, int COL0, bool MUL>
-__device__ __forceinline__ void scatter_chunk(const Chunk<K>& c, float* __restrict__ tile, float s) {
-  const int lane = lane_id();
+template <int K, int ROW, int COL0, bool MUL, int NT = WAVE>
+__device__ __forceinline__ void scatter_chunk(const Chunk<K, NT>& c, float* __restrict__ tile, float s) {
+  const int lane = NT == WAVE ? lane_id() : (int)threadIdx.x;
 #pragma unroll
-  for (int it = 0; it < Chunk<K>::ITERS; ++it) {
-    const int f = it * WAVE + lane;
-    if (!Chunk<K>::EXACT && f >= Chunk<K>::NF4) continue;
+  for (int it = 0; it < Chunk<K, NT>::ITERS; ++it) {
+    const int f = it * NT + lane;
+    if (!Chunk<K, NT>::EXACT && f >= Chunk<K, NT>::NF4) continue;
     const int e = 4 * f;
     float4 t = c.v[it];
     if (MUL) { t.x *= s; t.y *= s; t.z *= s; t.w *= s; }
@@ -73,17 +74,17 @@ __device__ __forceinline__ void scatter_chunk(const Chunk<K>& c, float* __restri
 }
 
 // Store the assembled (64 x ROW) LDS tile as one contiguous run of `valid` floats.
-template <int ROW, bool FULL>
+template <int ROW, bool FULL, int NT = WAVE>
 __device__ __forceinline__ void store_tile(const float* __restrict__ tile, float* __restrict__ dst, int valid) {
   constexpr int NF4 = (TILE * ROW) / 4;
-  constexpr int ITERS = (NF4 + WAVE - 1) / WAVE;
-  const int lane = lane_id();
+  constexpr int ITERS = (NF4 + NT - 1) / NT;
+  const int lane = NT == WAVE ? lane_id() : (int)threadIdx.x;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
-    const int f = it * WAVE + lane;
+    const int f = it * NT + lane;
     const int e = 4 * f;
     if (FULL) {
-      if ((NF4 % WAVE) == 0 || f < NF4)
+      if ((NF4 % NT) == 0 || f < NF4)
         *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(tile + e);
     } else if (f < NF4) {
       if (e + 3 < valid) {
