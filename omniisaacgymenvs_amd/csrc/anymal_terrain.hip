@@ -131,8 +131,12 @@ __global__ __launch_bounds__(1024) void anymal_command_norm_kernel(float* __rest
 // ------------------------------------------------------------------ main
 template <bool FULLTILE>
 __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __restrict__ lds, int64_t t, int nv) {
-  float* obs_t = lds;             // 64 x 188
-  float* s_pose = lds + TILE * AO;  // 64 x 6: yaw quat (w, z), base pos (x, y, z), pad
+  float* obs_t = lds;                       // 64 x 188
+  float* s_pose = lds + TILE * AO;           // 64 x float4: normalised yaw quat (w, z), base pos (x, y)
+  float* s_pz = s_pose + TILE * 4;           // 64: base z - 0.5
+  float* s_hx = s_pz + TILE;                 // 140 + 140: the scan grid (:173-187)
+  float* s_hy = s_hx + AP;
+  float* s_ns = s_hy + AP;                   // 188: noise_scale_vec (:157-171)
   const oige_anymal_params& p = a.p;
   const int tid = threadIdx.x;
   const int64_t env0 = t * TILE;
@@ -155,6 +159,19 @@ __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __r
     wg_for_each<AD, ANT>(c3, [&](int e, int c, float v) { obs_t[e * AO + C_LA + c] = v; });
     wg_for_each<AD, ANT>(c4, [&](int e, int c, float v) { obs_t[e * AO + C_LDV + c] = v; });
     wg_for_each<AD, ANT>(c5, [&](int e, int c, float v) { obs_t[e * AO + C_TQ + c] = v; });
+  }
+  if (step) {
+    if (tid < AP) {  // meshgrid(x, y, indexing='ij') flattened: k = ix * 10 + iy
+      const int ix = tid / 10, iy = tid % 10;
+      s_hx[tid] = 0.1f * (float)(ix < 7 ? ix - 8 : ix - 5);  // :178-180
+      s_hy[tid] = 0.1f * (float)(iy < 5 ? iy - 5 : iy - 4);  // :175-177
+    }
+    if (tid < AO) {
+      const int col = tid;
+      s_ns[tid] = col < 3 ? p.noise_scales[0] : col < 6 ? p.noise_scales[1] : col < 9 ? p.noise_scales[2]
+                : col < 12 ? 0.0f : col < 24 ? p.noise_scales[3] : col < 36 ? p.noise_scales[4]
+                : col < 176 ? p.noise_scales[5] : 0.0f;
+    }
   }
   __syncthreads();
 
@@ -369,34 +386,43 @@ __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __r
     // yaw-only quaternion (:609-611): zero x,y then normalize (4-wide row: unfused sum)
     const float yn = norm4(q4{hq.w, 0.0f, 0.0f, hq.z});
     const float yd = yn < 1e-9f ? 1e-9f : yn;
-    float* ps = s_pose + tid * 6;
-    ps[0] = hq.w / yd; ps[1] = hq.z / yd; ps[2] = 0.0f / yd;
-    ps[3] = hpos.x; ps[4] = hpos.y; ps[5] = hpos.z;
+    *reinterpret_cast<float4*>(s_pose + tid * 4) = make_float4(hq.w / yd, hq.z / yd, hpos.x, hpos.y);
+    s_pz[tid] = hpos.z - 0.5f;  // (:538) base z - 0.5, the same subtraction for each of the env's 140 points
   }
   if (!step) return;  // uniform across the workgroup
   __syncthreads();
 
   // ---- height scan (:582-604, :537-539): 64 x 140 points over 256 threads
+#ifndef OIGE_EXP_NO_SCAN
+  // quat_apply(q_yaw, (hx, hy, 0)) with q_yaw = (w, 0, 0, z) (:608-612), written out with the terms that are exactly
+  // zero removed (the surviving products, sums and their order are oige_math.hpp's quat_apply: t = 2 (qv x v);
+  // v + w t + qv x t), so every finite result is bit-identical:
+  //   t = (-(2 z hy), 2 z hx, 0)      qv x t = (-(z t.y), z t.x, 0)
+  const int hs_cols = p.hs_cols, max_r = p.hs_rows - 2, max_c = p.hs_cols - 2;
+#pragma unroll 2
   for (int pidx = tid; pidx < TILE * AP; pidx += ANT) {
-    const int e = pidx / AP, k = pidx % AP;
-    const int ix = k / 10, iy = k % 10;
-    const float hx = 0.1f * (float)(ix < 7 ? ix - 8 : ix - 5);  // :178-180
-    const float hy = 0.1f * (float)(iy < 5 ? iy - 5 : iy - 4);  // :175-177
-    const float* ps = s_pose + e * 6;
-    const q4 qy{ps[0], ps[2], ps[2], ps[1]};
-    const f3 rp = quat_apply(qy, f3{hx, hy, 0.0f});
-    const float wx = ((rp.x + ps[3]) + p.border_size) / p.horizontal_scale;
-    const float wy = ((rp.y + ps[4]) + p.border_size) / p.horizontal_scale;
-    long long px = (long long)wx, py = (long long)wy;  // .long(): truncation toward zero
-    px = px < 0 ? 0 : (px > p.hs_rows - 2 ? p.hs_rows - 2 : px);
-    py = py < 0 ? 0 : (py > p.hs_cols - 2 ? p.hs_cols - 2 : py);
-    const int16_t h1 = a.s.height_samples[px * p.hs_cols + py];
-    const int16_t h2 = a.s.height_samples[(px + 1) * p.hs_cols + (py + 1)];
+    const int e = pidx / AP, k = pidx - e * AP;
+    const float hx = s_hx[k], hy = s_hy[k];
+    const float4 ps = *reinterpret_cast<const float4*>(s_pose + e * 4);  // w, z, px, py
+    const float tx = -((ps.y * hy) * 2.0f), ty = (ps.y * hx) * 2.0f;
+    const float rx = (hx + ps.x * tx) + (-(ps.y * ty));
+    const float ry = (hy + ps.x * ty) + (ps.y * tx);
+    const float wx = ((rx + ps.z) + p.border_size) / p.horizontal_scale;  // :586-593
+    const float wy = ((ry + ps.w) + p.border_size) / p.horizontal_scale;
+    // .long() truncates toward zero; v_cvt_i32_f32 does too and saturates, and the clip that follows (:596-597) maps
+    // every saturated value where int64 truncation + clip would (out-of-range low -> 0, high -> rows - 2)
+    int px = (int)wx, py = (int)wy;
+    px = px < 0 ? 0 : (px > max_r ? max_r : px);
+    py = py < 0 ? 0 : (py > max_c ? max_c : py);
+    const int idx = px * hs_cols + py;
+    const int16_t h1 = a.s.height_samples[idx];
+    const int16_t h2 = a.s.height_samples[idx + hs_cols + 1];
     const float mh = (float)(h1 < h2 ? h1 : h2) * p.vertical_scale;
-    float hv = (ps[5] - 0.5f) - mh;
+    float hv = s_pz[e] - mh;
     hv = (hv != hv) ? hv : (hv < -1.0f ? -1.0f : (hv > 1.0f ? 1.0f : hv));
     obs_t[e * AO + 36 + k] = hv * p.height_meas_scale;
   }
+#endif
   __syncthreads();
 
   // ---- D: obs tile -> HBM with the uniform noise (:438-439)
@@ -408,6 +434,7 @@ __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __r
     const int e = 4 * f;
     if (!FULLTILE && e >= nv * AO) continue;  // AO % 4 == 0: a float4 is wholly valid or wholly not
     float4 v = *reinterpret_cast<const float4*>(obs_t + e);
+#ifndef OIGE_EXP_NO_NOISE
     if (p.add_noise) {
       const int c = e % AO;  // 4 consecutive columns of one row; region boundaries are multiples of 4 except 3/6/9
       float uu[4];
@@ -420,17 +447,14 @@ __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __r
         const u4 x = philox4x32_10(cc, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
         uu[0] = u01(x.x); uu[1] = u01(x.y); uu[2] = u01(x.z); uu[3] = u01(x.w);
       }
+      const float4 sc = *reinterpret_cast<const float4*>(s_ns + c);
       float vv[4] = {v.x, v.y, v.z, v.w};
+      const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int col = c + k;
-        const float sc = col < 3 ? p.noise_scales[0] : col < 6 ? p.noise_scales[1] : col < 9 ? p.noise_scales[2]
-                       : col < 12 ? 0.0f : col < 24 ? p.noise_scales[3] : col < 36 ? p.noise_scales[4]
-                       : col < 176 ? p.noise_scales[5] : 0.0f;
-        vv[k] = vv[k] + (2.0f * uu[k] - 1.0f) * sc;
-      }
+      for (int k = 0; k < 4; ++k) vv[k] = vv[k] + (2.0f * uu[k] - 1.0f) * scv[k];
       v = make_float4(vv[0], vv[1], vv[2], vv[3]);
     }
+#endif
     *reinterpret_cast<float4*>(a.b.obs_buf + env0 * AO + e) = v;
   }
 }
@@ -545,7 +569,7 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
   if (int rc = launch_scan_groups(num_envs, b.reset_workspace, st)) return rc;
   hipLaunchKernelGGL(anymal_command_norm_kernel, dim3(1), dim3(1024), 0, st, b.reduce_workspace, T);
   if (int rc = check_launch("anymal_command_norm_kernel")) return rc;
-  const size_t lds = sizeof(float) * (TILE * AO + TILE * 6);
+  const size_t lds = sizeof(float) * (TILE * AO + TILE * 4 + TILE + 2 * AP + AO);
   hipLaunchKernelGGL(anymal_post_kernel, dim3((unsigned)T), dim3(ANT), lds, st, a);
   if (int rc = check_launch("anymal_post_kernel")) return rc;
   hipLaunchKernelGGL(anymal_extras_kernel, dim3(1), dim3(1024), 0, st, a);

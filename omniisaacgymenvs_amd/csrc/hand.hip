@@ -82,74 +82,116 @@ __device__ __forceinline__ float wave_sum_f(float v) {
   return v;
 }
 
-// OBS: 0 openai, 2 full.  ASYM: also states_buf.
-template <int OBS, bool ASYM, bool FULLTILE>
-__device__ __forceinline__ void hand_post_tile(const HandPost& a, float* __restrict__ lds, int64_t t, int nv) {
-  constexpr int OW = OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157;
-  constexpr bool NEED_FULLCOLS = ASYM || OBS == OIGE_HAND_OBS_FULL;  // dof/ft_rot/ft_vel columns wanted
-  // LDS carve: [obs tile | states tile | env_pos 64x3 | lo 24 | hi 24]
-  float* obs_t = lds;
-  float* st_t = lds + TILE * OW;
-  float* s_env = st_t + (ASYM ? TILE * HS : 0);
-  float* s_lo = s_env + TILE * 3;
-  float* s_hi = s_lo + HD;
+// ---- post_physics tile passes ------------------------------------------------------------------------------
+// A 64-env tile is processed as two passes of HTE = 32 envs: the LDS a workgroup needs halves (~30 KB with the
+// asymmetric states), so five workgroups (20 waves) stay resident per CU instead of two (the register budget is kept
+// under 102 VGPRs for that: one pass's loads in flight at a time).  Per-tile results (reset / goal-reset counts, the two partial
+// sums of compute_hand_reward) accumulate over the passes and are written once.
+constexpr int HTE = 32;
+// keeps the scheduler from hoisting every scatter's LDS address arithmetic above the first one (200 VGPRs -> spills)
+#ifdef OIGE_NO_SCHED_FENCE
+#define OIGE_SCHED_FENCE()
+#else
+#define OIGE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
-  const oige_hand_params& p = a.p;
-  const int tid = threadIdx.x;
-  const int64_t env0 = t * TILE;
+#ifndef OIGE_HAND_TE
+#define OIGE_HAND_TE HTE
+#endif
+constexpr int HPE = OIGE_HAND_TE;  // envs per pass (64 = the whole tile in one pass)
+
+template <bool NEED_FULLCOLS, bool ASYM>
+struct HandLoads {
+  WgChunk<HD, HNT, HPE> c_dpos, c_dvel;
+  WgChunk<3 * HF, HNT, HPE> c_ftp;
+  WgChunk<4 * HF, HNT, HPE> c_ftr;
+  WgChunk<6 * HF, HNT, HPE> c_ftv, c_sens;
+  WgChunk<HA, HNT, HPE> c_act;
+  f3 epos, opos, olin, oang, gpos;
+  q4 orot, grot;
+  int64_t reset_in, reset_goal_in, progress;
+  float successes;
+};
+
+struct HandTileAcc {
+  int n_reset, n_goal;
+  float nres, fin;
+};
+
+// OBS: 0 openai, 2 full.  ASYM: also states_buf.
+template <int OBS, bool ASYM, bool FULL>
+__device__ __forceinline__ void hand_post_load(const HandPost& a, int64_t env0, int nv,
+                                               HandLoads<ASYM || OBS == OIGE_HAND_OBS_FULL, ASYM>& L, const int tid) {
+  constexpr bool NEED_FULLCOLS = ASYM || OBS == OIGE_HAND_OBS_FULL;  // dof/ft_rot/ft_vel columns wanted
   const bool do_progress = a.stages & OIGE_STAGE_PROGRESS;
   const bool do_metrics = a.stages & OIGE_STAGE_METRICS;
-
-  // ---- A: loads in flight
-  WgChunk<HD, HNT> c_dpos, c_dvel;
-  WgChunk<3 * HF, HNT> c_ftp;
-  WgChunk<4 * HF, HNT> c_ftr;
-  WgChunk<6 * HF, HNT> c_ftv, c_sens;
-  WgChunk<HA, HNT> c_act;
   if (a.stages & OIGE_STAGE_OBS) {
-    wg_load_chunk<3 * HF, HNT, FULLTILE>(c_ftp, a.s.fingertip_pos + env0 * 3 * HF, nv * 3 * HF);
-    wg_load_chunk<HA, HNT, FULLTILE>(c_act, a.b.actions + env0 * HA, nv * HA);
+    wg_load_chunk<3 * HF, HNT, FULL, HPE>(L.c_ftp, a.s.fingertip_pos + env0 * 3 * HF, nv * 3 * HF, tid);
+    wg_load_chunk<HA, HNT, FULL, HPE>(L.c_act, a.b.actions + env0 * HA, nv * HA, tid);
     if (NEED_FULLCOLS) {
-      wg_load_chunk<HD, HNT, FULLTILE>(c_dpos, a.s.hand_dof_pos + env0 * HD, nv * HD);
-      wg_load_chunk<HD, HNT, FULLTILE>(c_dvel, a.s.hand_dof_vel + env0 * HD, nv * HD);
-      wg_load_chunk<4 * HF, HNT, FULLTILE>(c_ftr, a.s.fingertip_rot + env0 * 4 * HF, nv * 4 * HF);
-      wg_load_chunk<6 * HF, HNT, FULLTILE>(c_ftv, a.s.fingertip_velocities + env0 * 6 * HF, nv * 6 * HF);
+      wg_load_chunk<HD, HNT, FULL, HPE>(L.c_dpos, a.s.hand_dof_pos + env0 * HD, nv * HD, tid);
+      wg_load_chunk<HD, HNT, FULL, HPE>(L.c_dvel, a.s.hand_dof_vel + env0 * HD, nv * HD, tid);
+      wg_load_chunk<4 * HF, HNT, FULL, HPE>(L.c_ftr, a.s.fingertip_rot + env0 * 4 * HF, nv * 4 * HF, tid);
+      wg_load_chunk<6 * HF, HNT, FULL, HPE>(L.c_ftv, a.s.fingertip_velocities + env0 * 6 * HF, nv * 6 * HF, tid);
     }
-    if (ASYM) wg_load_chunk<6 * HF, HNT, FULLTILE>(c_sens, a.s.vec_sensor + env0 * 6 * HF, nv * 6 * HF);
+    if (ASYM) wg_load_chunk<6 * HF, HNT, FULL, HPE>(L.c_sens, a.s.vec_sensor + env0 * 6 * HF, nv * 6 * HF, tid);
   }
-
-  // per-env rows (wave 0: one env per lane)
-  const bool envlane = tid < TILE;
-  const bool live = envlane && (FULLTILE || tid < nv);
+  // per-env rows (first lanes of wave 0: one env per lane)
+  const bool live = tid < HPE && (FULL || tid < nv);
   const int64_t env = env0 + tid;
-  f3 epos{0, 0, 0}, opos{0, 0, 0}, olin{0, 0, 0}, oang{0, 0, 0}, gpos{0, 0, 0};
-  q4 orot{1, 0, 0, 0}, grot{1, 0, 0, 0};
-  int64_t reset_in = 0, reset_goal_in = 0, progress = 0;
-  float successes = 0.f;
+  L.epos = L.opos = L.olin = L.oang = L.gpos = f3{0, 0, 0};
+  L.orot = L.grot = q4{1, 0, 0, 0};
+  L.reset_in = L.reset_goal_in = L.progress = 0;
+  L.successes = 0.f;
   if (live) {
     const float* e3 = a.s.env_pos + env * 3;
-    epos = f3{e3[0], e3[1], e3[2]};
+    L.epos = f3{e3[0], e3[1], e3[2]};
     const float* o3 = a.s.object_pos + env * 3;
-    opos = f3{o3[0], o3[1], o3[2]};
+    L.opos = f3{o3[0], o3[1], o3[2]};
     const float4 r4 = *reinterpret_cast<const float4*>(a.s.object_rot + env * 4);
-    orot = q4{r4.x, r4.y, r4.z, r4.w};
+    L.orot = q4{r4.x, r4.y, r4.z, r4.w};
     if (a.stages & OIGE_STAGE_OBS) {
       const float2* vp = reinterpret_cast<const float2*>(a.s.object_velocities + env * 6);
       const float2 v0 = vp[0], v1 = vp[1], v2 = vp[2];
-      olin = f3{v0.x, v0.y, v1.x};
-      oang = f3{v1.y, v2.x, v2.y};
+      L.olin = f3{v0.x, v0.y, v1.x};
+      L.oang = f3{v1.y, v2.x, v2.y};
     }
     const float* g3 = a.b.goal_pos + env * 3;
-    gpos = f3{g3[0], g3[1], g3[2]};
+    L.gpos = f3{g3[0], g3[1], g3[2]};
     const float4 g4 = *reinterpret_cast<const float4*>(a.b.goal_rot + env * 4);
-    grot = q4{g4.x, g4.y, g4.z, g4.w};
-    if (do_progress || do_metrics) progress = a.b.progress_buf[env];
+    L.grot = q4{g4.x, g4.y, g4.z, g4.w};
+    if (do_progress || do_metrics) L.progress = a.b.progress_buf[env];
     if (do_metrics) {
-      reset_in = a.b.reset_buf[env];
-      reset_goal_in = a.b.reset_goal_buf[env];
-      successes = a.b.successes[env];
+      L.reset_in = a.b.reset_buf[env];
+      L.reset_goal_in = a.b.reset_goal_buf[env];
+      L.successes = a.b.successes[env];
     }
   }
+}
+
+template <int OBS, bool ASYM, bool FULL>
+__device__ __forceinline__ void hand_post_process(const HandPost& a, float* __restrict__ lds, int64_t env0, int nv,
+                                                  const HandLoads<ASYM || OBS == OIGE_HAND_OBS_FULL, ASYM>& L,
+                                                  HandTileAcc& acc, const int tid) {
+  constexpr int OW = OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157;
+  constexpr bool NEED_FULLCOLS = ASYM || OBS == OIGE_HAND_OBS_FULL;
+  // LDS carve: [obs tile | states tile | env_pos HPEx3 | lo 24 | hi 24]
+  float* obs_t = lds;
+  float* st_t = lds + HPE * OW;
+  float* s_env = st_t + (ASYM ? HPE * HS : 0);
+  float* s_lo = s_env + HPE * 3;
+  float* s_hi = s_lo + HD;
+
+  const oige_hand_params& p = a.p;
+  const bool do_progress = a.stages & OIGE_STAGE_PROGRESS;
+  const bool do_metrics = a.stages & OIGE_STAGE_METRICS;
+  const bool envlane = tid < HPE;
+  const bool live = envlane && (FULL || tid < nv);
+  const int64_t env = env0 + tid;
+  const f3 epos = L.epos, opos = L.opos, olin = L.olin, oang = L.oang, gpos = L.gpos;
+  const q4 orot = L.orot, grot = L.grot;
+  int64_t progress = L.progress;
+
   if (envlane) {
     s_env[tid * 3 + 0] = epos.x;
     s_env[tid * 3 + 1] = epos.y;
@@ -163,46 +205,52 @@ __device__ __forceinline__ void hand_post_tile(const HandPost& a, float* __restr
 
   // ---- B: pass-through columns
   if (a.stages & OIGE_STAGE_OBS) {
-    wg_for_each<3 * HF, HNT>(c_ftp, [&](int e, int c, float v) {
+    wg_for_each<3 * HF, HNT, HPE>(L.c_ftp, [&](int e, int c, float v) {
       const float w = v - s_env[e * 3 + (c % 3)];  // fingertip_pos -= env_pos (shadow_hand.py:124-126)
       if (OBS == OIGE_HAND_OBS_OPENAI) obs_t[e * OW + c] = w;
       if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + 72 + c] = w;
       if (ASYM) st_t[e * HS + 72 + c] = w;
-    });
-    wg_for_each<HA, HNT>(c_act, [&](int e, int c, float v) {
+    }, tid);
+    OIGE_SCHED_FENCE();
+    wg_for_each<HA, HNT, HPE>(L.c_act, [&](int e, int c, float v) {
       if (OBS == OIGE_HAND_OBS_OPENAI) obs_t[e * OW + 22 + c] = v;
       if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + 137 + c] = v;
       if (ASYM) st_t[e * HS + 167 + c] = v;
-    });
+    }, tid);
+    OIGE_SCHED_FENCE();
     if (NEED_FULLCOLS) {
-      wg_for_each<HD, HNT>(c_dpos, [&](int e, int c, float v) {
+      wg_for_each<HD, HNT, HPE>(L.c_dpos, [&](int e, int c, float v) {
         const float w = unscale(v, s_lo[c], s_hi[c]);
         if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + c] = w;
         if (ASYM) st_t[e * HS + c] = w;
-      });
-      wg_for_each<HD, HNT>(c_dvel, [&](int e, int c, float v) {
+      }, tid);
+      OIGE_SCHED_FENCE();
+      wg_for_each<HD, HNT, HPE>(L.c_dvel, [&](int e, int c, float v) {
         const float w = p.vel_obs_scale * v;
         if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + HD + c] = w;
         if (ASYM) st_t[e * HS + HD + c] = w;
-      });
-      wg_for_each<4 * HF, HNT>(c_ftr, [&](int e, int c, float v) {
+      }, tid);
+      OIGE_SCHED_FENCE();
+      wg_for_each<4 * HF, HNT, HPE>(L.c_ftr, [&](int e, int c, float v) {
         if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + 87 + c] = v;
         if (ASYM) st_t[e * HS + 87 + c] = v;
-      });
-      wg_for_each<6 * HF, HNT>(c_ftv, [&](int e, int c, float v) {
+      }, tid);
+      OIGE_SCHED_FENCE();
+      wg_for_each<6 * HF, HNT, HPE>(L.c_ftv, [&](int e, int c, float v) {
         if (OBS == OIGE_HAND_OBS_FULL) obs_t[e * OW + 107 + c] = v;
         if (ASYM) st_t[e * HS + 107 + c] = v;
-      });
+      }, tid);
+      OIGE_SCHED_FENCE();
     }
     if (ASYM)
-      wg_for_each<6 * HF, HNT>(c_sens, [&](int e, int c, float v) { st_t[e * HS + 137 + c] = p.force_torque_obs_scale * v; });
+      wg_for_each<6 * HF, HNT, HPE>(L.c_sens, [&](int e, int c, float v) { st_t[e * HS + 137 + c] = p.force_torque_obs_scale * v; }, tid);
   }
 
   // ---- C: per-env math (wave 0)
   float action_penalty = 0.f;
-  if (envlane) {
+  if (tid < WAVE) {
     const f3 opl{opos.x - epos.x, opos.y - epos.y, opos.z - epos.z};  // object_pos -= env_pos (:258)
-    if (a.stages & OIGE_STAGE_OBS) {
+    if ((a.stages & OIGE_STAGE_OBS) && envlane) {
       const q4 rel = quat_mul(orot, quat_conjugate(grot));
       if (OBS == OIGE_HAND_OBS_OPENAI) {
         float* r = obs_t + tid * OW;
@@ -239,7 +287,7 @@ __device__ __forceinline__ void hand_post_tile(const HandPost& a, float* __restr
           action_penalty += s3;
         }
       }
-      const HandRewardOut o = hand_reward(a, opl, orot, gpos, grot, action_penalty, reset_in, reset_goal_in, progress, successes);
+      const HandRewardOut o = hand_reward(a, opl, orot, gpos, grot, action_penalty, L.reset_in, L.reset_goal_in, progress, L.successes);
       if (live) {
         a.b.rew_buf[env] = o.reward;
         a.b.reset_buf[env] = o.resets;
@@ -251,14 +299,10 @@ __device__ __forceinline__ void hand_post_tile(const HandPost& a, float* __restr
       const bool r1 = live && o.resets != 0, g1 = live && o.goal_resets != 0;
       const unsigned long long mr = __ballot(r1), mg = __ballot(g1);
       // Sum(resets) counts VALUES (a stale reset_buf could hold values other than 0/1)
-      const float nres = wave_sum_f(live ? (float)o.resets : 0.f);
-      const float fin = wave_sum_f(live ? o.successes * (float)o.resets : 0.f);  // :523
-      if (tid == 0) {
-        a.b.reset_workspace[t] = __popcll(mr);
-        a.b.goal_workspace[t] = __popcll(mg);
-        a.b.reduce_workspace[2 * t + 0] = nres;
-        a.b.reduce_workspace[2 * t + 1] = fin;
-      }
+      acc.n_reset += __popcll(mr);
+      acc.n_goal += __popcll(mg);
+      acc.nres += wave_sum_f(live ? (float)o.resets : 0.f);
+      acc.fin += wave_sum_f(live ? o.successes * (float)o.resets : 0.f);  // :523
     } else if (do_progress && live) {
       a.b.progress_buf[env] = progress;
     }
@@ -267,13 +311,46 @@ __device__ __forceinline__ void hand_post_tile(const HandPost& a, float* __restr
 
   // ---- D: tiles -> HBM
   if (a.stages & OIGE_STAGE_OBS) {
-    wg_store_tile<OW, HNT, FULLTILE>(obs_t, a.b.obs_buf + env0 * OW, nv * OW);
-    if (ASYM) wg_store_tile<HS, HNT, FULLTILE>(st_t, a.b.states_buf + env0 * HS, nv * HS);
+    wg_store_tile<OW, HNT, FULL, HPE>(obs_t, a.b.obs_buf + env0 * OW, nv * OW, tid);
+    if (ASYM) wg_store_tile<HS, HNT, FULL, HPE>(st_t, a.b.states_buf + env0 * HS, nv * HS, tid);
   }
 }
 
+template <int OBS, bool ASYM, bool FULL>
+__device__ __forceinline__ void hand_post_tile(const HandPost& a, float* __restrict__ lds, int64_t t, int left) {
+  constexpr int PASSES = TILE / HPE;
+  HandTileAcc acc{0, 0, 0.f, 0.f};
+#pragma unroll 1
+  for (int h = 0; h < PASSES; ++h) {
+    const int rest = left - h * HPE;
+    const int nv = FULL ? HPE : (rest < 0 ? 0 : (rest > HPE ? HPE : rest));
+    if (FULL || nv > 0) {
+      // the thread id is laundered once per pass: everything derived from it (every LDS scatter address) would
+      // otherwise be loop-invariant, and hoisting ~100 addresses out of the pass loop costs the occupancy this
+      // two-pass scheme is for
+      int tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      HandLoads<ASYM || OBS == OIGE_HAND_OBS_FULL, ASYM> L;
+      hand_post_load<OBS, ASYM, FULL>(a, t * TILE + h * HPE, nv, L, tid);
+      hand_post_process<OBS, ASYM, FULL>(a, lds, t * TILE + h * HPE, nv, L, acc, tid);
+    }
+    if (h + 1 < PASSES) __syncthreads();  // the LDS tiles are reused by the next pass
+  }
+  if ((a.stages & OIGE_STAGE_METRICS) && threadIdx.x == 0) {
+    a.b.reset_workspace[t] = acc.n_reset;
+    a.b.goal_workspace[t] = acc.n_goal;
+    a.b.reduce_workspace[2 * t + 0] = acc.nres;
+    a.b.reduce_workspace[2 * t + 1] = acc.fin;
+  }
+}
+
+#ifdef OIGE_HAND_WAVES_PER_EU
+#define OIGE_HAND_OCC __attribute__((amdgpu_waves_per_eu(OIGE_HAND_WAVES_PER_EU)))
+#else
+#define OIGE_HAND_OCC
+#endif
 template <int OBS, bool ASYM>
-__global__ __launch_bounds__(HNT) void hand_post_kernel(const HandPost a) {
+__global__ __launch_bounds__(HNT) OIGE_HAND_OCC void hand_post_kernel(const HandPost a) {
   extern __shared__ __align__(16) float lds[];
   const int64_t t = blockIdx.x;
   const int64_t left = a.n - t * TILE;
@@ -642,7 +719,7 @@ static int check_hand(const oige_hand_params* p, const oige_hand_buffers* b, int
 template <int OBS, bool ASYM>
 static int launch_hand_post(const HandPost& a, hipStream_t s) {
   constexpr int OW = OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157;
-  const size_t lds = sizeof(float) * (TILE * OW + (ASYM ? TILE * HS : 0) + TILE * 3 + 2 * HD);
+  const size_t lds = sizeof(float) * (HPE * OW + (ASYM ? HPE * HS : 0) + HPE * 3 + 2 * HD);
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hand_post_kernel<OBS, ASYM>),

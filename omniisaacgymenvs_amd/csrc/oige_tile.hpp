@@ -106,22 +106,24 @@ __device__ __forceinline__ void store_tile(const float* __restrict__ tile, float
 // tile is ~48 KB of LDS: four waves per tile keep 8-12 waves per CU resident instead of 2-3.
 namespace oige {
 
-template <int K, int NT>
+// TE = envs per pass (64 = a whole tile; 32 = half a tile, which halves the LDS a workgroup needs).
+template <int K, int NT, int TE = TILE>
 struct WgChunk {
-  static constexpr int NF4 = (TILE * K) / 4;
+  static constexpr int NF4 = (TE * K) / 4;
   static constexpr int ITERS = (NF4 + NT - 1) / NT;
+  static_assert((TE * K) % 4 == 0, "a pass's run must be a whole number of float4");
   float4 v[ITERS];
 };
 
-template <int K, int NT, bool FULL>
-__device__ __forceinline__ void wg_load_chunk(WgChunk<K, NT>& c, const float* __restrict__ src, int valid) {
-  const int tid = threadIdx.x;
+template <int K, int NT, bool FULL, int TE = TILE>
+__device__ __forceinline__ void wg_load_chunk(WgChunk<K, NT, TE>& c, const float* __restrict__ src, int valid,
+                                              const int tid = threadIdx.x) {
 #pragma unroll
-  for (int it = 0; it < WgChunk<K, NT>::ITERS; ++it) {
+  for (int it = 0; it < WgChunk<K, NT, TE>::ITERS; ++it) {
     const int f = it * NT + tid;
     const int e = 4 * f;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f < WgChunk<K, NT>::NF4) {
+    if (f < WgChunk<K, NT, TE>::NF4) {
       if (FULL || e + 3 < valid) {
         t = *reinterpret_cast<const float4*>(src + e);
       } else {
@@ -134,14 +136,13 @@ __device__ __forceinline__ void wg_load_chunk(WgChunk<K, NT>& c, const float* __
   }
 }
 
-// fn(env_in_tile, column, value) for every element of the run this thread holds
-template <int K, int NT, typename F>
-__device__ __forceinline__ void wg_for_each(const WgChunk<K, NT>& c, F&& fn) {
-  const int tid = threadIdx.x;
+// fn(env_in_pass, column, value) for every element of the run this thread holds
+template <int K, int NT, int TE = TILE, typename F>
+__device__ __forceinline__ void wg_for_each(const WgChunk<K, NT, TE>& c, F&& fn, const int tid = threadIdx.x) {
 #pragma unroll
-  for (int it = 0; it < WgChunk<K, NT>::ITERS; ++it) {
+  for (int it = 0; it < WgChunk<K, NT, TE>::ITERS; ++it) {
     const int f = it * NT + tid;
-    if (f >= WgChunk<K, NT>::NF4) continue;
+    if (f >= WgChunk<K, NT, TE>::NF4) continue;
     const int e = 4 * f;
     const float tv[4] = {c.v[it].x, c.v[it].y, c.v[it].z, c.v[it].w};
 #pragma unroll
@@ -152,11 +153,12 @@ __device__ __forceinline__ void wg_for_each(const WgChunk<K, NT>& c, F&& fn) {
   }
 }
 
-template <int ROW, int NT, bool FULL>
-__device__ __forceinline__ void wg_store_tile(const float* __restrict__ tile, float* __restrict__ dst, int valid) {
-  constexpr int NF4 = (TILE * ROW) / 4;
+template <int ROW, int NT, bool FULL, int TE = TILE>
+__device__ __forceinline__ void wg_store_tile(const float* __restrict__ tile, float* __restrict__ dst, int valid,
+                                              const int tid = threadIdx.x) {
+  constexpr int NF4 = (TE * ROW) / 4;
+  static_assert((TE * ROW) % 4 == 0, "a pass's output run must be a whole number of float4");
   constexpr int ITERS = (NF4 + NT - 1) / NT;
-  const int tid = threadIdx.x;
 #pragma unroll
   for (int it = 0; it < ITERS; ++it) {
     const int f = it * NT + tid;
