@@ -5,9 +5,19 @@
 world steps -> ``task.post_physics_step`` -> observation DR -> states -> clamp / device hop ->
 ``({"obs", "states"}, rew, resets, extras)``.  ``reset()`` flags every env and steps once with
 zero actions.  The recording branch (:55-70) needs a renderer and is reduced to its counters.
+
+``fused_io`` (default True) removes the wrapper's extra full passes over actions / obs / states without
+changing a value the policy sees:
+  * ``torch.clamp(actions)`` (:77) is folded into the task's pre_physics kernel where it supports that;
+  * with DR, the noise kernel writes the clamped copy in the same launch (:94-97 + :40 in one pass);
+  * ``torch.clamp(x, -inf, inf)`` (clip key absent: Ant, Humanoid, AnymalTerrain's states) is skipped: the task's
+    buffer itself is returned instead of a fresh copy of it.  A caller that keeps ``obs`` across ``step`` calls
+    without copying it (rl_games copies it into its experience buffer first) should set ``fused_io = False``,
+    which restores the reference's allocate-per-step behaviour.
 """
 from __future__ import annotations
 
+import math
 from datetime import datetime
 
 import torch
@@ -16,13 +26,31 @@ from .vec_env_base import VecEnvBase
 
 
 class VecEnvRLGames(VecEnvBase):
+    fused_io = True
+    _obs_is_clamped = False
+
+    def _clamp_obs(self, x):
+        t = self._task
+        if self.fused_io and math.isinf(t.clip_obs):
+            return x  # clamp(x, -inf, inf) == x: no pass, no copy
+        return torch.clamp(x, -t.clip_obs, t.clip_obs)
+
     def _process_data(self):
         t = self._task
-        self._obs = torch.clamp(self._obs, -t.clip_obs, t.clip_obs).to(t.rl_device)
+        if not self._obs_is_clamped:
+            self._obs = self._clamp_obs(self._obs)
+        self._obs = self._obs.to(t.rl_device)
         self._rew = self._rew.to(t.rl_device)
-        self._states = torch.clamp(self._states, -t.clip_obs, t.clip_obs).to(t.rl_device)
+        self._states = self._clamp_obs(self._states).to(t.rl_device)
         self._resets = self._resets.to(t.rl_device)
         self._extras = self._extras
+
+    def _persistent(self, name, like):
+        buf = getattr(self, name, None)
+        if buf is None or buf.shape != like.shape or buf.device != like.device:
+            buf = torch.empty_like(like)
+            setattr(self, name, buf)
+        return buf
 
     def set_task(self, task, backend="numpy", sim_params=None, init_sim=True, rendering_dt=1.0 / 60.0) -> None:
         super().set_task(task, backend, sim_params, init_sim, rendering_dt)
@@ -46,19 +74,38 @@ class VecEnvRLGames(VecEnvBase):
                 self.step_count = 0
             self.step_count += 1
 
-        if t.randomize_actions:
-            actions = t._dr_randomizer.apply_actions_randomization(actions=actions, reset_buf=t.reset_buf)
-
-        actions = torch.clamp(actions, -t.clip_actions, t.clip_actions).to(t.device)
+        fused = self.fused_io and actions.device == torch.device(t.device) and actions.dtype == torch.float32
+        finite_act_clip = not math.isinf(t.clip_actions)
+        t.clamp_actions_in_kernel = False
+        if t.randomize_actions and fused and finite_act_clip and actions.is_contiguous():
+            clamped = self._persistent("_act_clamped", actions)  # noise + clamp in one launch
+            t._dr_randomizer.apply_actions_randomization(actions=actions, reset_buf=t.reset_buf, clamped_out=clamped,
+                                                         clip=t.clip_actions)
+            actions = clamped
+        else:
+            if t.randomize_actions:
+                actions = t._dr_randomizer.apply_actions_randomization(actions=actions, reset_buf=t.reset_buf)
+            if fused and t.supports_action_clamp:
+                t.clamp_actions_in_kernel = finite_act_clip  # the pre_physics kernel clamps (or there is nothing to clamp)
+                actions = actions.to(t.device)
+            else:
+                actions = torch.clamp(actions, -t.clip_actions, t.clip_actions).to(t.device)
 
         t.pre_physics_step(actions)
+        t.clamp_actions_in_kernel = False
         self._advance_world(to_render)
         self._obs, self._rew, self._resets, self._extras = t.post_physics_step()
 
+        self._obs_is_clamped = False
         if t.randomize_observations:
-            self._obs = t._dr_randomizer.apply_observations_randomization(
-                observations=self._obs.to(device=t.rl_device), reset_buf=t.reset_buf
-            )
+            obs = self._obs.to(device=t.rl_device)
+            if self.fused_io and not math.isinf(t.clip_obs) and obs.is_contiguous():
+                clamped = self._persistent("_obs_clamped", obs)  # noise + clamp in one launch
+                t._dr_randomizer.apply_observations_randomization(observations=obs, reset_buf=t.reset_buf,
+                                                                  clamped_out=clamped, clip=t.clip_obs)
+                self._obs, self._obs_is_clamped = clamped, True
+            else:
+                self._obs = t._dr_randomizer.apply_observations_randomization(observations=obs, reset_buf=t.reset_buf)
 
         self._states = t.get_states()
         self._process_data()

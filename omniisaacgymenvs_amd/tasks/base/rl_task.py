@@ -50,6 +50,12 @@ class RLTask:
 
         self._env = env
         self.is_extension = False
+        # fast path of VecEnvRLGames (envs/vec_env_rlgames.py): tasks whose pre_physics kernel can fold the wrapper's
+        # torch.clamp(actions, -clip, clip) (vec_env_rlgames.py:77) set supports_action_clamp; the wrapper then turns
+        # clamp_actions_in_kernel on instead of clamping with torch
+        if not hasattr(self, "supports_action_clamp"):
+            self.supports_action_clamp = False
+        self.clamp_actions_in_kernel = False
 
         for attr, default in (
             ("_num_agents", 1),

@@ -28,6 +28,7 @@ class InHandManipulationTask(RLTask):
         self.fused = True
         self.sync_free = True
         self._step_count = 0
+        self.supports_action_clamp = True
         RLTask.__init__(self, name, env)
 
         n, dev = self.num_envs, self.device
@@ -335,6 +336,8 @@ class InHandManipulationTask(RLTask):
                    self.reset_goal_buf.data_ptr(), self.reset_goal_buf._version)
             if key == self._counts_key:
                 flags |= _lib.PRE_COUNTS_VALID
+        if self.clamp_actions_in_kernel:
+            flags |= _lib.PRE_CLAMP_ACTIONS  # the wrapper's clamp (vec_env_rlgames.py:77), folded into the kernel
         p, b, r = self._params(), self._buffers(), self._reset_io()
         rc = _lib.load().oige_hand_pre_physics(
             C.byref(p), actions.data_ptr(), C.byref(b), C.byref(r), self.actions.data_ptr(), self._targets_out.data_ptr(),

@@ -39,6 +39,7 @@ class LocomotionTask(RLTask):
         self.sync_free = True    # pre_physics_step without the host read of len(reset_env_ids)
         self.materialize_vecs = True  # write up_vec / heading_vec back (locomotion.py:90-91)
         self._step_count = 0
+        self.supports_action_clamp = True
         RLTask.__init__(self, name, env)
 
     def update_config(self):
@@ -238,6 +239,8 @@ class LocomotionTask(RLTask):
                 self.reset_idx(o["env_ids"][:num].clone())
         elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key:
             flags |= _lib.PRE_COUNTS_VALID  # the DONE stage's tile counts still describe reset_buf
+        if self.clamp_actions_in_kernel:
+            flags |= _lib.PRE_CLAMP_ACTIONS  # the wrapper's clamp (vec_env_rlgames.py:77), folded into the kernel
         p, b, r = self._params(), self._buffers(), self._reset_io()
         rc = _lib.load().oige_locomotion_pre_physics(
             C.byref(p), actions.data_ptr(), C.byref(b), C.byref(r), self.actions.data_ptr(), self._forces.data_ptr(),
