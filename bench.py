@@ -313,12 +313,20 @@ def main() -> None:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        # OIGE_DIST_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices,
+        # the statistics all-reduce runs over gloo on the host); the real runs use RCCL (backend "nccl" on ROCm)
+        backend = os.environ.get("OIGE_DIST_BACKEND", "nccl")
+        gpu = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(gpu)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{gpu}"))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         dist = None
+        gpu = 0
         torch.cuda.set_device(0)
-    dev = f"cuda:{local_rank if world > 1 else 0}"
+    dev = f"cuda:{gpu}"
 
     from omniisaacgymenvs_amd.utils import distributed as od
 
@@ -344,6 +352,9 @@ def main() -> None:
         after()
     torch.cuda.synchronize()
     if dist is not None:
+        # first use of the communicator (RCCL sets its rings up lazily): keep that out of the timed region
+        t = bench.task
+        od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -359,7 +370,7 @@ def main() -> None:
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -49,6 +49,8 @@ def local_stats(rew_buf: torch.Tensor, reset_buf: torch.Tensor, progress_buf: to
 def all_reduce_stats(stats: torch.Tensor) -> Dict[str, float]:
     """Sum over ranks (one 40-byte collective; no-op without an initialised process group) -> whole-job means."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if stats.is_cuda and dist.get_backend() != "nccl":
+            stats = stats.cpu()  # gloo rehearsal of a GPU run: reduce on the host
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     s = stats.tolist()
     n, done = max(s[4], 1.0), max(s[1], 1.0)
