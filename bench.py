@@ -334,32 +334,35 @@ def main() -> None:
     with contextlib.redirect_stdout(sys.stderr):  # the task constructors print like the reference's; stdout carries ONE JSON line
         bench = ADAPTERS[args.task](args.task, n, dev, od.rank_seed(1234, rank))
 
-    ev_pairs = []
+    # HIP events around the post kernel of every timed step.  They are CREATED here: hipEventCreate inside the loop costs
+    # ~100 us per step (measured), recording a ready-made one does not.
+    ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     after = getattr(bench, "after_post", lambda: None)
 
-    def timed_step():
+    def timed_step(es, e0, e1):
+        es.record()
         bench.pre()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()  # torch's current stream == the stream the kernels are launched on (_lib.current_stream)
         bench.post()
         e1.record()
         after()
-        ev_pairs.append((e0, e1))
 
     for _ in range(args.warmup):
         bench.pre()
         bench.post()
         after()
     torch.cuda.synchronize()
+    # first use of torch's reduction kernels (lazy code-object load) and of the communicator (RCCL sets its rings up
+    # lazily): keep both out of the timed region
+    t = bench.task
+    od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
     if dist is not None:
-        # first use of the communicator (RCCL sets its rings up lazily): keep that out of the timed region
-        t = bench.task
-        od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        timed_step()
+    for es, (e0, e1) in zip(ev_start, ev_pairs):
+        timed_step(es, e0, e1)
     # episode statistics [sum reward, n done, sum episode length of done envs, successes, n envs]: the path's only
     # cross-rank exchange, one 40-byte all-reduce over RCCL (utils/distributed.py)
     t = bench.task
@@ -375,6 +378,8 @@ def main() -> None:
         elapsed = float(t.item())
 
     post_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
+    pre_ms = sum(es.elapsed_time(e0) for es, (e0, _) in zip(ev_start, ev_pairs)) / len(ev_pairs)
+    gpu_span_ms = ev_start[0].elapsed_time(ev_pairs[-1][1]) / len(ev_pairs)  # first pre launch -> last post end, per step
     copy_gbs = measured_copy_gbs(dev, bench.post_bytes * n) if rank == 0 else None
     achieved = bench.post_bytes * n / (post_ms * 1e-3) / 1e9
     traffic = None
@@ -407,6 +412,7 @@ def main() -> None:
                 "bound": "hbm", "kernel": bench.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_env": bench.post_bytes, "avg_kernel_ms": post_ms,
+                "pre_physics_ms": pre_ms, "gpu_ms_per_step": gpu_span_ms,
                 "measured_copy_gbs": copy_gbs,
                 "frac_of_measured_copy_12_streams": achieved / copy_gbs["streams_12"],
             },
