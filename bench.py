@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- fused obs+reward+reset env-steps/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal]
 
 One "step" = one pre_physics_step (reset-id compaction, reset of the flagged envs, action scaling /
 PD torques) + one post_physics_step (progress, obs, reward, done[, in-step reset]) over a batch of
@@ -245,9 +245,57 @@ class AnymalBench:
         return step
 
 
-ADAPTERS = {"Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
-DEFAULT_ENVS = {"Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
-CPU_ENVS = {"Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
+class AnymalFlatBench:
+    """Anymal on flat ground (obs 48, 6-term reward, non-sticky done, position targets)."""
+
+    def __init__(self, name, n, dev, seed):
+        from helpers import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+
+        self.env, self.task = make_task("Anymal", n, device=dev, seed=seed)
+        t = self.task
+        st = workloads.anymal_flat_state(n, t.default_dof_pos, device=dev, seed=seed)
+        workloads.load_anymal_flat_state(t, st)
+        t._anymals.apply_resets = False
+        self.actions = st["actions"]
+        self.post_bytes = 312 + 308  # csrc/anymal.hip header
+        self.kernel = "anymal_flat_post_kernel"
+        self.workload = f"Anymal (flat) obs(48)+reward+reset fused, {n} envs per GPU, synthetic root/DOF state"
+        self.extra_cfg = {"num_dof": 12}
+
+    def pre(self):
+        self.task.pre_physics_step(self.actions)
+
+    def post(self):
+        self.task.post_physics_step()
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from oracle import anymal_oracle as an
+
+        spec = an.AnymalFlatSpec()
+        default = torch.tensor(an.DEFAULT_JOINT_ANGLES).repeat(n, 1)
+        st = workloads.anymal_flat_state(n, default, device="cpu", seed=1234)
+        b = an.AnymalFlatBuffers(torch.zeros(n, 48), torch.zeros(n), st["reset"].clone(), st["progress"].clone(), st["commands"].clone(),
+                                 st["actions"].clone(), st["last_actions"].clone(), st["last_dof_vel"].clone(),
+                                 st["current_targets"].clone(), default)
+        lower, upper = default[0] - 1.0, default[0] + 1.0
+        draw = lambda ids: (torch.rand(len(ids), 12), torch.rand(len(ids), 1), torch.rand(len(ids), 1), torch.rand(len(ids), 1))
+
+        def step():
+            an.pre_physics(spec, b, st["actions"], lower, upper, st["pos"], st["rot"], draw=draw)
+            an.post_physics(spec, b, st["pos"], st["rot"], st["vel"], st["dof_pos"], st["dof_vel"])
+
+        return step
+
+
+ADAPTERS = {"Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
+DEFAULT_ENVS = {"Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
+CPU_ENVS = {"Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
 def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:
@@ -299,7 +347,7 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the BASELINE.json config's per-GPU size)")
-    ap.add_argument("--task", default="Ant", choices=list(ADAPTERS))
+    ap.add_argument("--task", default="Ant", choices=sorted(ADAPTERS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-envs", type=int, default=0)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),

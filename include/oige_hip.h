@@ -418,6 +418,76 @@ int oige_anymal_reset_idx(const oige_anymal_params* params, const oige_anymal_st
                           const oige_anymal_buffers* buffers, const oige_anymal_reset_io* reset_io,
                           int64_t num_envs, oige_stream_t stream);
 
+/* ------------------------------------------------------------------ Anymal (flat ground)
+ * tasks/anymal.py.  Scalars: update_config (:51-101), cfg/task/Anymal.yaml.          */
+#define OIGE_ANYMAL_FLAT_OBS 48
+
+typedef struct oige_anymal_flat_params {
+  float lin_vel_scale, ang_vel_scale, dof_pos_scale, dof_vel_scale;
+  float action_scale;
+  float dt;                    /* 1/60 (:90) */
+  float base_threshold;        /* 0.51, is_base_below_threshold(threshold=0.51, ground_heights=0.0) (:307) */
+  float clip_actions;          /* with OIGE_PRE_CLAMP_ACTIONS */
+  int32_t max_episode_length;  /* int(episodeLength_s / dt + 0.5) (:92) */
+  int32_t reserved0;
+  float rew_scales[6];         /* lin_vel_xy, ang_vel_z, lin_vel_z, joint_acc, action_rate, cosmetic, each x dt (:96-97) */
+  float cmd_lo[3], cmd_span[3];/* x, y, yaw: lower and (upper - lower) folded in double (:217-225) */
+  float default_dof_pos[OIGE_ANYMAL_DOFS];
+  float dof_lower[OIGE_ANYMAL_DOFS];
+  float dof_upper[OIGE_ANYMAL_DOFS];
+} oige_anymal_flat_params;
+
+typedef struct oige_anymal_flat_state { /* view getters of :144-147 / :275-278; read-only */
+  const float* base_pos;    /* (N,3) */
+  const float* base_rot;    /* (N,4) */
+  const float* velocities;  /* (N,6) */
+  const float* dof_pos;     /* (N,12) */
+  const float* dof_vel;     /* (N,12) */
+} oige_anymal_flat_state;
+
+typedef struct oige_anymal_flat_buffers {
+  float* obs_buf;           /* (N,48) */
+  float* rew_buf;           /* (N,) */
+  int64_t* reset_buf;       /* (N,) */
+  int64_t* progress_buf;    /* (N,) */
+  float* commands;          /* (N,3) x, y, yaw (:250-253) */
+  const float* actions;     /* (N,12) the task's self.actions */
+  float* last_actions;      /* (N,12) */
+  float* last_dof_vel;      /* (N,12) */
+  float* current_targets;   /* (N,12); pre_physics / reset_idx only */
+  int32_t* reset_workspace; /* oige_workspace_ints(N): tile counts of reset_buf */
+} oige_anymal_flat_buffers;
+
+typedef struct oige_anymal_flat_reset_io {
+  const float* initial_root_pos; /* (N,3) */
+  const float* initial_root_rot; /* (N,4) */
+  const float* u_vel;            /* NULL, or (n,12) pre-drawn U[0,1): 1st draw (:199) */
+  const float* u_cmd;            /* NULL, or (n,3): 2nd-4th draws x, y, yaw (:217-225) */
+  uint64_t seed;
+  uint64_t step;
+  int64_t* env_ids;              /* out (N,) == reset_buf.nonzero().squeeze(-1) (in for oige_anymal_flat_reset_idx) */
+  int64_t* count;                /* out device scalar (in for oige_anymal_flat_reset_idx) */
+  float* dof_pos_out;            /* out (n,12) */
+  float* dof_vel_out;            /* out (n,12) */
+  float* root_pos_out;           /* out (n,3) */
+  float* root_rot_out;           /* out (n,4) */
+  float* root_vel_out;           /* out (n,6) zeros */
+} oige_anymal_flat_reset_io;
+
+/* RLTask.post_physics_step (rl_task.py:289-295) for AnymalTask: progress += 1, get_observations (:143-178),
+ * calculate_metrics (:274-309, refreshes last_actions / last_dof_vel), is_done (:311-314).  `stages` as for locomotion. */
+int oige_anymal_flat_post_physics(const oige_anymal_flat_params* params, const oige_anymal_flat_state* state,
+                                  const oige_anymal_flat_buffers* buffers, int64_t num_envs, uint32_t stages,
+                                  oige_stream_t stream);
+/* pre_physics_step (:180-194): compaction of reset_buf, reset_idx of the flagged envs, actions clone, position targets */
+int oige_anymal_flat_pre_physics(const oige_anymal_flat_params* params, const float* actions_in,
+                                 const oige_anymal_flat_buffers* buffers, const oige_anymal_flat_reset_io* reset_io,
+                                 float* actions_out, int64_t num_envs, uint32_t flags, oige_stream_t stream);
+/* reset_idx(env_ids) (:196-231) with caller-provided ids and, optionally, torch-drawn noise */
+int oige_anymal_flat_reset_idx(const oige_anymal_flat_params* params, const oige_anymal_flat_buffers* buffers,
+                               const oige_anymal_flat_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                               oige_stream_t stream);
+
 /* ------------------------------------------------------------------ observation / action noise
  * utils/domain_randomization/randomize.py:283-410 (the part of Randomizer that is task math).      */
 #define OIGE_NOISE_ADDITIVE 0

@@ -155,6 +155,30 @@ class AnymalResetIO(C.Structure):
     ]
 
 
+class AnymalFlatParams(C.Structure):
+    _fields_ = [
+        ("lin_vel_scale", _f), ("ang_vel_scale", _f), ("dof_pos_scale", _f), ("dof_vel_scale", _f), ("action_scale", _f),
+        ("dt", _f), ("base_threshold", _f), ("clip_actions", _f), ("max_episode_length", C.c_int32), ("reserved0", C.c_int32),
+        ("rew_scales", _f * 6), ("cmd_lo", _f * 3), ("cmd_span", _f * 3), ("default_dof_pos", _f * 12), ("dof_lower", _f * 12),
+        ("dof_upper", _f * 12),
+    ]
+
+
+class AnymalFlatState(C.Structure):
+    _fields_ = [(n, _fp) for n in ("base_pos", "base_rot", "velocities", "dof_pos", "dof_vel")]
+
+
+class AnymalFlatBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "commands", "actions", "last_actions",
+                                   "last_dof_vel", "current_targets", "reset_workspace")]
+
+
+class AnymalFlatResetIO(C.Structure):
+    _fields_ = [("initial_root_pos", _fp), ("initial_root_rot", _fp), ("u_vel", _fp), ("u_cmd", _fp), ("seed", C.c_uint64),
+                ("step", C.c_uint64), ("env_ids", _fp), ("count", _fp), ("dof_pos_out", _fp), ("dof_vel_out", _fp),
+                ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp)]
+
+
 NOISE_ADDITIVE, NOISE_SCALING = 0, 1
 NOISE_GAUSSIAN, NOISE_UNIFORM, NOISE_LOGUNIFORM = 0, 1, 2
 
@@ -201,6 +225,12 @@ SIGNATURES = {
                                       C.c_int64, _P]),
     "oige_hand_reset_target_pose": (C.c_int, [C.POINTER(HandParams), C.POINTER(HandBuffers), C.POINTER(HandResetIO),
                                               C.c_int64, C.c_int64, _P]),
+    "oige_anymal_flat_post_physics": (C.c_int, [C.POINTER(AnymalFlatParams), C.POINTER(AnymalFlatState),
+                                                C.POINTER(AnymalFlatBuffers), C.c_int64, C.c_uint32, _P]),
+    "oige_anymal_flat_pre_physics": (C.c_int, [C.POINTER(AnymalFlatParams), _P, C.POINTER(AnymalFlatBuffers),
+                                               C.POINTER(AnymalFlatResetIO), _P, C.c_int64, C.c_uint32, _P]),
+    "oige_anymal_flat_reset_idx": (C.c_int, [C.POINTER(AnymalFlatParams), C.POINTER(AnymalFlatBuffers),
+                                             C.POINTER(AnymalFlatResetIO), C.c_int64, C.c_int64, _P]),
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "oige_dr_noise_count": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_dr_noise_apply": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),

@@ -185,3 +185,38 @@ def load_anymal_state(task, st: Dict[str, Tensor]) -> None:
     task.terrain_types.copy_(st["terrain_types"].to(dev))
     task.env_origins.copy_(st["env_origins"].to(dev))
     task.progress_buf.copy_(st["progress"].to(dev))
+
+
+def anymal_flat_state(n: int, default_dof_pos: Tensor, device="cpu", seed: int = 1234) -> Dict[str, Tensor]:
+    """Anymal on flat ground: base height U(0.35, 0.75) (~40 % below the 0.51 fall threshold is too
+    much for a steady state, so z is drawn from U(0.49, 0.75): ~8 % fall per step), progress up to the 3000-step episode."""
+    g = _gen(device, seed)
+    f = dict(device=device, dtype=torch.float32, generator=g)
+    quat = torch.randn(n, 4, **f)
+    quat = (quat / quat.norm(dim=-1, keepdim=True)).contiguous()
+    pos = torch.cat([torch.randn(n, 2, **f) * 3.0, torch.rand(n, 1, **f) * 0.26 + 0.49], dim=-1).contiguous()
+    return dict(
+        pos=pos, rot=quat, vel=torch.randn(n, 6, **f),
+        dof_pos=(default_dof_pos.to(device)[:1] + torch.randn(n, 12, **f) * 0.3).contiguous(), dof_vel=torch.randn(n, 12, **f) * 2.0,
+        commands=(torch.rand(n, 3, **f) * 2.0 - 1.0), actions=torch.rand(n, 12, **f) * 2.0 - 1.0,
+        last_actions=torch.rand(n, 12, **f) * 2.0 - 1.0, last_dof_vel=torch.randn(n, 12, **f) * 2.0,
+        current_targets=(default_dof_pos.to(device)[:1] + torch.randn(n, 12, **f) * 0.2).contiguous(),
+        progress=torch.randint(0, 3001, (n,), device=device, generator=g, dtype=torch.int64),
+        reset=(torch.rand(n, **f) < 0.1).long(),
+    )
+
+
+def load_anymal_flat_state(task, st: Dict[str, Tensor]) -> None:
+    dev, v = task.device, task._anymals
+    v.positions.copy_(st["pos"].to(dev))
+    v.orientations.copy_(st["rot"].to(dev))
+    v.velocities.copy_(st["vel"].to(dev))
+    v.joint_positions.copy_(st["dof_pos"].to(dev))
+    v.joint_velocities.copy_(st["dof_vel"].to(dev))
+    task.commands.copy_(st["commands"].to(dev))
+    task.actions.copy_(st["actions"].to(dev))
+    task.last_actions.copy_(st["last_actions"].to(dev))
+    task.last_dof_vel.copy_(st["last_dof_vel"].to(dev))
+    task.current_targets.copy_(st["current_targets"].to(dev))
+    task.progress_buf.copy_(st["progress"].to(dev))
+    task.reset_buf.copy_(st["reset"].to(dev))

@@ -42,6 +42,13 @@ class SyntheticAnymalView(SyntheticArticulationView):
                          dof_names={n: i for i, n in enumerate(ANYMAL_DOF_NAMES)})
         self._knees = SyntheticContactView("knees_view", count * 4, device)
         self._base = SyntheticContactView("base_view", count, device)
+        self.dof_names = list(ANYMAL_DOF_NAMES)
+
+    def is_base_below_threshold(self, threshold, ground_heights):  # views/anymal_view.py:76-80
+        base_pos, _ = self.get_world_poses()
+        base_heights = base_pos[:, 2]
+        base_heights -= ground_heights
+        return base_heights[:] < threshold
 
 
 class AnymalTerrainTask(RLTask):

@@ -147,6 +147,30 @@ TASK_DEFAULTS["AnymalTerrain"] = {
             "default_physics_material": {"static_friction": 1.0, "dynamic_friction": 1.0, "restitution": 0.0}},
 }
 
+# cfg/task/Anymal.yaml:7-66
+TASK_DEFAULTS["Anymal"] = {
+    "name": "Anymal",
+    "env": {
+        "numEnvs": 4096, "envSpacing": 4.0, "clipObservations": 5.0, "clipActions": 1.0, "controlFrequencyInv": 2,
+        "baseInitState": {"pos": [0.0, 0.0, 0.62], "rot": [0.0, 0.0, 0.0, 1.0], "vLinear": [0.0, 0.0, 0.0],
+                          "vAngular": [0.0, 0.0, 0.0]},
+        "randomCommandVelocityRanges": {"linear_x": [-2.0, 2.0], "linear_y": [-1.0, 1.0], "yaw": [-1.0, 1.0]},
+        "control": {"stiffness": 85.0, "damping": 2.0, "actionScale": 13.5},
+        "defaultJointAngles": {
+            "LF_HAA": 0.03, "LH_HAA": 0.03, "RF_HAA": -0.03, "RH_HAA": -0.03,
+            "LF_HFE": 0.4, "LH_HFE": -0.4, "RF_HFE": 0.4, "RH_HFE": -0.4,
+            "LF_KFE": -0.8, "LH_KFE": 0.8, "RF_KFE": -0.8, "RH_KFE": 0.8,
+        },
+        "learn": {
+            "linearVelocityXYRewardScale": 1.0, "angularVelocityZRewardScale": 0.5, "linearVelocityZRewardScale": -0.03,
+            "jointAccRewardScale": -0.0003, "actionRateRewardScale": -0.006, "cosmeticRewardScale": -0.06,
+            "linearVelocityScale": 2.0, "angularVelocityScale": 0.25, "dofPositionScale": 1.0, "dofVelocityScale": 0.05,
+            "episodeLength_s": 50,
+        },
+    },
+    "sim": {"dt": 0.01, "add_ground_plane": True, "add_distant_light": False, "enable_cameras": False},
+}
+
 
 def task_config(name: str, num_envs: Optional[int] = None, **env_overrides: Any) -> Dict[str, Any]:
     cfg = copy.deepcopy(TASK_DEFAULTS[name])
