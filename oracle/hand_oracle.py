@@ -10,13 +10,15 @@ Restates, op for op:
     (openai 42, full 157, full_no_vel 77 incl. its overlapping-slice quirk at :190-191, and the
     asymmetric full_state states_buf 187; the non-asymmetric full_state obs :263-306 is dead code
     in the reference -- undefined dof_force_tensor -- and is not restated).
+  * the AllegroHand packers tasks/allegro_hand.py:101-144 (``hand="allegro"``: 16 DOFs, all
+    actuated, no fingertips, no states; full 72 / full_no_vel 50).
 Inputs are const: the reference's in-place ``object_pos -= env_pos`` on view buffers is restated
 as a subtraction into a temporary.
 
 Pinning: compute_hand_reward / randomize_rotation are executed from the reference's source on
 the restated omni helpers (helper layer UNPINNED, composition pinned); the packers and
 reset/pre_physics arithmetic are executed from the reference's method source on a stub ``self``
-(tests/test_oracle_pinned_hand.py, container only).
+(tests/test_oracle_pinned_hand.py, container only), ShadowHand and AllegroHand alike.
 """
 from __future__ import annotations
 
@@ -41,6 +43,7 @@ ACTUATED_DOF_INDICES = [i for i in range(24) if i not in (5, 9, 13, 18)]
 class HandSpec:
     """cfg/task/ShadowHand.yaml:7-49 defaults; ShadowHandOpenAI_FF.yaml:36-51 via openai_ff()."""
 
+    hand: str = "shadow"  # "shadow" (tasks/shadow_hand.py) | "allegro" (tasks/allegro_hand.py)
     num_hand_dofs: int = 24
     num_actions: int = 20
     num_fingertips: int = 5
@@ -73,12 +76,15 @@ class HandSpec:
 
     def __post_init__(self):
         if self.lower is None:
-            g = torch.Generator().manual_seed(24)
-            self.lower = -(0.2 + 0.6 * torch.rand(24, generator=g))
-            self.upper = 0.3 + 1.3 * torch.rand(24, generator=g)
+            nd = self.num_hand_dofs
+            g = torch.Generator().manual_seed(nd)
+            self.lower = -(0.2 + 0.6 * torch.rand(nd, generator=g))
+            self.upper = 0.3 + 1.3 * torch.rand(nd, generator=g)
 
     @property
     def num_obs(self) -> int:
+        if self.hand == "allegro":
+            return {"full_no_vel": 50, "full": 72}[self.obs_type]  # allegro_hand.py:62-65
         return {"openai": 42, "full_no_vel": 77, "full": 157, "full_state": 187}[self.obs_type]
 
     @property
@@ -92,6 +98,13 @@ def openai_ff_spec() -> HandSpec:
     return HandSpec(obs_type="openai", asymmetric_obs=True, fall_penalty=-50.0, success_tolerance=0.4,
                     max_consecutive_successes=50, av_factor=0.1, act_moving_average=0.3,
                     max_episode_length=int(round(8.0 / (3 * (1.0 / 60)))))
+
+
+def allegro_spec(obs_type: str = "full") -> HandSpec:
+    """cfg/task/AllegroHand.yaml:7-42 (same reward scalars as ShadowHand.yaml); 16 DOFs, all actuated
+    (views/allegro_hand_view.py:53), no fingertip bodies, no states (allegro_hand.py:69-71)."""
+    return HandSpec(hand="allegro", num_hand_dofs=16, num_actions=16, num_fingertips=0, obs_type=obs_type,
+                    actuated_dof_indices=list(range(16)))
 
 
 def randomize_rotation(rand0, rand1, x_unit_tensor, y_unit_tensor):
@@ -141,12 +154,12 @@ class HandState:
     object_pos: Tensor          # (N,3)
     object_rot: Tensor          # (N,4)
     object_velocities: Tensor   # (N,6)
-    fingertip_pos: Tensor       # (5N,3)
-    fingertip_rot: Tensor       # (5N,4)
-    fingertip_velocities: Tensor  # (5N,6)
-    hand_dof_pos: Tensor        # (N,24)
-    hand_dof_vel: Tensor        # (N,24)
-    vec_sensor: Tensor          # (N,5,6)
+    fingertip_pos: Optional[Tensor]       # (5N,3); None for AllegroHand
+    fingertip_rot: Optional[Tensor]       # (5N,4)
+    fingertip_velocities: Optional[Tensor]  # (5N,6)
+    hand_dof_pos: Tensor        # (N,24|16)
+    hand_dof_vel: Tensor        # (N,24|16)
+    vec_sensor: Optional[Tensor]          # (N,5,6)
     env_pos: Tensor             # (N,3)
 
 
@@ -185,9 +198,31 @@ def observations(spec: HandSpec, s: HandState, b: HandBuffers) -> None:
     object_pos = s.object_pos - s.env_pos
     object_rot = s.object_rot
     object_linvel, object_angvel = s.object_velocities[:, 0:3], s.object_velocities[:, 3:6]
-    fingertip_pos = s.fingertip_pos - s.env_pos.repeat((1, nf)).reshape(n * nf, 3)
     rel = tu.quat_mul(object_rot, tu.quat_conjugate(b.goal_rot))
     o = b.obs_buf
+    if spec.hand == "allegro":  # allegro_hand.py:101-144
+        o[:, 0:nd] = tu.unscale(s.hand_dof_pos, spec.lower, spec.upper)
+        if spec.obs_type == "full_no_vel":  # :118-128
+            o[:, 16:19] = object_pos
+            o[:, 19:23] = object_rot
+            o[:, 23:26] = b.goal_pos
+            o[:, 26:30] = b.goal_rot
+            o[:, 30:34] = rel
+            o[:, 34:50] = b.actions
+        elif spec.obs_type == "full":  # :130-144
+            o[:, nd:2 * nd] = spec.vel_obs_scale * s.hand_dof_vel
+            o[:, 32:35] = object_pos
+            o[:, 35:39] = object_rot
+            o[:, 39:42] = object_linvel
+            o[:, 42:45] = spec.vel_obs_scale * object_angvel
+            o[:, 45:48] = b.goal_pos
+            o[:, 48:52] = b.goal_rot
+            o[:, 52:56] = rel
+            o[:, 56:72] = b.actions
+        else:
+            raise RuntimeError("AllegroHand observationType must be full or full_no_vel (allegro_hand.py:59)")
+        return
+    fingertip_pos = s.fingertip_pos - s.env_pos.repeat((1, nf)).reshape(n * nf, 3)
     if spec.obs_type == "openai":  # :162-165
         o[:, 0:15] = fingertip_pos.reshape(n, 15)
         o[:, 15:18] = object_pos
