@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- fused obs+reward+reset env-steps/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand]
 
 One "step" = one pre_physics_step (reset-id compaction, reset of the flagged envs, action scaling /
 PD torques) + one post_physics_step (progress, obs, reward, done[, in-step reset]) over a batch of
@@ -245,6 +245,58 @@ class AnymalBench:
         return step
 
 
+class AllegroHandBench:
+    """AllegroHand, `full` obs(72) + goal-rotation reward + resets (the YAML has no DR section)."""
+
+    def __init__(self, name, n, dev, seed):
+        from helpers import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+
+        self.env, self.task = make_task("AllegroHand", n, device=dev, seed=seed)
+        t = self.task
+        st = workloads.hand_state(n, t._env_pos, t.goal_pos, t.hand_dof_lower_limits, t.hand_dof_upper_limits, device=dev, seed=seed,
+                                  num_actions=16, fingertips=0)
+        workloads.load_hand_state(t, st)
+        for v in (t._hands, t._objects, t._goals):
+            v.apply_resets = False
+        self.actions = st["actions"]
+        self.post_bytes = 312 + 320  # csrc/hand.hip header
+        self.kernel = "allegro_post_kernel"
+        self.workload = f"AllegroHand full obs(72) + goal-rotation reward + reset_target_pose/reset_idx, {n} envs per GPU, synthetic state"
+        self.extra_cfg = {"observationType": t.obs_type, "num_dof": 16}
+
+    def pre(self):
+        self.task.pre_physics_step(self.actions)
+
+    def post(self):
+        self.task.post_physics_step()
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from oracle import hand_oracle as ho
+
+        spec = ho.allegro_spec("full")
+        env_pos = torch.zeros(n, 3)
+        goal_pos = torch.tensor([0.0, -0.2, 0.52]).repeat(n, 1)
+        st = workloads.hand_state(n, env_pos, goal_pos, spec.lower, spec.upper, device="cpu", seed=1234, num_actions=16, fingertips=0)
+        s = ho.HandState(st["object_pos"], st["object_rot"], st["object_vel"], None, None, None, st["dof_pos"], st["dof_vel"], None, env_pos)
+        b = ho.HandBuffers(torch.zeros(n, 72), torch.zeros(n, 0), torch.zeros(n), st["reset"].clone(), st["reset_goal"].clone(),
+                           st["progress"].clone(), st["successes"].clone(), torch.zeros(1), goal_pos.clone(), st["goal_rot"].clone(),
+                           st["actions"].clone(), torch.zeros(n, 16), torch.zeros(n, 16))
+        init = ho.HandInit(goal_pos.clone(), goal_pos.clone(), env_pos, torch.zeros(16), torch.zeros(16))
+        u = lambda ids, k: 2.0 * torch.rand(len(ids), k) - 1.0
+
+        def step():
+            ho.pre_physics(spec, b, init, st["actions"], draw_goal=lambda ids: u(ids, 4), draw_reset=lambda ids: (u(ids, 37), u(ids, 4)))
+            ho.post_physics(spec, s, b)
+
+        return step
+
+
 class AnymalFlatBench:
     """Anymal on flat ground (obs 48, 6-term reward, non-sticky done, position targets)."""
 
@@ -293,9 +345,9 @@ class AnymalFlatBench:
         return step
 
 
-ADAPTERS = {"Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
-DEFAULT_ENVS = {"Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
-CPU_ENVS = {"Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
+ADAPTERS = {"AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
+DEFAULT_ENVS = {"AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
+CPU_ENVS = {"AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
 def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:

@@ -174,11 +174,17 @@ int oige_locomotion_reset_idx(const oige_locomotion_params* params, const oige_l
                               const oige_locomotion_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
                               oige_stream_t stream);
 
-/* ------------------------------------------------------------------ ShadowHand / in-hand manipulation
- * tasks/shared/in_hand_manipulation.py (reward, resets, action scaling) and
- * tasks/shadow_hand.py (observation packers).  Scalars: update_config (:63-97), ShadowHand.yaml.  */
+/* ------------------------------------------------------------------ ShadowHand / AllegroHand in-hand manipulation
+ * tasks/shared/in_hand_manipulation.py (reward, resets, action scaling), tasks/shadow_hand.py and
+ * tasks/allegro_hand.py (observation packers).  Scalars: update_config (:63-97), ShadowHand.yaml,
+ * AllegroHand.yaml.  obs_type also selects the hand: the ALLEGRO values mean 16 DOFs, all actuated
+ * (views/allegro_hand_view.py:53), no fingertip / sensor inputs, no states_buf; every (N,24) / (N,20)
+ * array below is then (N,16) and the u_reset table is (ne, 37).                                       */
 #define OIGE_HAND_OBS_OPENAI 0 /* 42 cols, shadow_hand.py:162-165 */
 #define OIGE_HAND_OBS_FULL 2   /* 157 cols, shadow_hand.py:198-217 */
+#define OIGE_HAND_OBS_ALLEGRO_FULL_NO_VEL 3 /* 50 cols, allegro_hand.py:118-128 */
+#define OIGE_HAND_OBS_ALLEGRO_FULL 4        /* 72 cols, allegro_hand.py:130-144 */
+#define OIGE_ALLEGRO_DOFS 16
 #define OIGE_HAND_DOFS 24
 #define OIGE_HAND_ACTIONS 20
 #define OIGE_HAND_FINGERTIPS 5

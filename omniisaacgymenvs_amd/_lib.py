@@ -115,6 +115,7 @@ class HandResetIO(C.Structure):
     ]
 
 HAND_OBS_OPENAI, HAND_OBS_FULL = 0, 2
+HAND_OBS_ALLEGRO_FULL_NO_VEL, HAND_OBS_ALLEGRO_FULL = 3, 4
 
 
 AR_TERMINATION, AR_LIN_VEL_XY, AR_LIN_VEL_Z, AR_ANG_VEL_Z, AR_ANG_VEL_XY, AR_ORIENT, AR_TORQUE, AR_JOINT_ACC, \

@@ -1,4 +1,8 @@
-// ShadowHand / in-hand manipulation per-step task math for gfx950 (MI355X).
+// ShadowHand / AllegroHand in-hand manipulation per-step task math for gfx950 (MI355X).
+//
+// AllegroHand (tasks/allegro_hand.py:101-144: 16 DOFs, all actuated, no fingertip bodies, no states) shares the reward,
+// reset and action-scaling code below (instantiated for 16 DOFs) and has its own one-wave-per-tile post kernel:
+// 632 algorithmic bytes per env-step with the `full` 72-column observation.
 //
 // Replaces, behind the unchanged InHandManipulationTask / ShadowHandTask method contract:
 //   get_observations    tasks/shadow_hand.py:120-262 (openai 42 / full 157 obs, asymmetric states 187)
@@ -360,6 +364,161 @@ __global__ __launch_bounds__(HNT) OIGE_HAND_OCC void hand_post_kernel(const Hand
     hand_post_tile<OBS, ASYM, false>(a, lds, t, (int)left);
 }
 
+// ---- AllegroHand post_physics (allegro_hand.py:101-144 + compute_hand_reward) --------------------------------
+// One wavefront per tile of 64 envs.  dof_pos / dof_vel / actions arrive as lane-linear float4 runs; with 16 columns
+// a lane's float4 always covers the same four DOFs (column = 4*lane mod 16), so its unscale limits are loop-invariant.
+constexpr int AD = OIGE_ALLEGRO_DOFS;  // 16 DOFs = 16 actions
+
+template <int OW, int COL0>
+__device__ __forceinline__ void allegro_put4(float* __restrict__ tile, int envl, int col, const float4 v) {
+  float* d = tile + envl * OW + COL0 + col;
+  if ((OW % 4 == 0) && (COL0 % 4 == 0)) {
+    *reinterpret_cast<float4*>(d) = v;
+  } else {
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+}
+
+template <int OBS, bool FULL>
+__device__ __forceinline__ void allegro_post_tile(const HandPost& a, float* __restrict__ tile, int64_t t, int nv) {
+  constexpr bool VEL = OBS == OIGE_HAND_OBS_ALLEGRO_FULL;
+  constexpr int OW = VEL ? 72 : 50;
+  constexpr int C_OBJ = VEL ? 32 : 16, C_ACT = VEL ? 56 : 34;
+  const oige_hand_params& p = a.p;
+  const int lane = lane_id();
+  const int64_t env0 = t * TILE;
+  const int64_t env = env0 + lane;
+  const bool live = FULL || lane < nv;
+  const bool do_progress = a.stages & OIGE_STAGE_PROGRESS, do_obs = a.stages & OIGE_STAGE_OBS;
+  const bool do_metrics = a.stages & OIGE_STAGE_METRICS;
+
+  // ---- A: loads in flight
+  Chunk<AD> c_pos, c_vel, c_act;
+  if (do_obs) {
+    load_chunk<AD, FULL>(c_pos, a.s.hand_dof_pos + env0 * AD, nv * AD);
+    if (VEL) load_chunk<AD, FULL>(c_vel, a.s.hand_dof_vel + env0 * AD, nv * AD);
+    load_chunk<AD, FULL>(c_act, a.b.actions + env0 * AD, nv * AD);
+  }
+  f3 epos{0, 0, 0}, opos{0, 0, 0}, olin{0, 0, 0}, oang{0, 0, 0}, gpos{0, 0, 0};
+  q4 orot{1, 0, 0, 0}, grot{1, 0, 0, 0};
+  int64_t reset_in = 0, reset_goal_in = 0, progress = 0;
+  float successes = 0.f, action_penalty = 0.f;
+  if (live) {
+    const float* e3 = a.s.env_pos + env * 3;
+    epos = f3{e3[0], e3[1], e3[2]};
+    const float* o3 = a.s.object_pos + env * 3;
+    opos = f3{o3[0], o3[1], o3[2]};
+    const float4 r4 = *reinterpret_cast<const float4*>(a.s.object_rot + env * 4);
+    orot = q4{r4.x, r4.y, r4.z, r4.w};
+    if (do_obs && VEL) {
+      const float2* vp = reinterpret_cast<const float2*>(a.s.object_velocities + env * 6);
+      const float2 v0 = vp[0], v1 = vp[1], v2 = vp[2];
+      olin = f3{v0.x, v0.y, v1.x};
+      oang = f3{v1.y, v2.x, v2.y};
+    }
+    const float* g3 = a.b.goal_pos + env * 3;
+    gpos = f3{g3[0], g3[1], g3[2]};
+    const float4 g4 = *reinterpret_cast<const float4*>(a.b.goal_rot + env * 4);
+    grot = q4{g4.x, g4.y, g4.z, g4.w};
+    if (do_progress || do_metrics) progress = a.b.progress_buf[env];
+    if (do_metrics) {
+      reset_in = a.b.reset_buf[env];
+      reset_goal_in = a.b.reset_goal_buf[env];
+      successes = a.b.successes[env];
+      const float4* ar = reinterpret_cast<const float4*>(a.b.actions + env * AD);  // torch.sum(actions**2, dim=-1) (:493)
+#pragma unroll
+      for (int k = 0; k < AD / 4; ++k) {
+        const float4 v = ar[k];
+        const float s0 = v.x * v.x, s1 = v.y * v.y, s2 = v.z * v.z, s3 = v.w * v.w;
+        action_penalty = k == 0 ? s0 : action_penalty + s0;
+        action_penalty += s1;
+        action_penalty += s2;
+        action_penalty += s3;
+      }
+    }
+  }
+
+  // ---- B: DOF / action columns into the tile
+  const f3 opl{opos.x - epos.x, opos.y - epos.y, opos.z - epos.z};  // object_pos -= env_pos (in_hand_manipulation.py:258)
+  if (do_obs) {
+    const int col = (4 * lane) & (AD - 1);
+    float lo[4], hi[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // selects over the scalar kernel arguments (a lane-indexed read would spill the table)
+      lo[q] = col == 0 ? p.dof_lower[q] : col == 4 ? p.dof_lower[4 + q] : col == 8 ? p.dof_lower[8 + q] : p.dof_lower[12 + q];
+      hi[q] = col == 0 ? p.dof_upper[q] : col == 4 ? p.dof_upper[4 + q] : col == 8 ? p.dof_upper[8 + q] : p.dof_upper[12 + q];
+    }
+#pragma unroll
+    for (int it = 0; it < Chunk<AD>::ITERS; ++it) {
+      const int envl = (it * WAVE + lane) >> 2;  // 4 float4 per 16-float row
+      const float4 q4v = c_pos.v[it];
+      allegro_put4<OW, 0>(tile, envl, col,
+                          make_float4(unscale(q4v.x, lo[0], hi[0]), unscale(q4v.y, lo[1], hi[1]), unscale(q4v.z, lo[2], hi[2]),
+                                      unscale(q4v.w, lo[3], hi[3])));  // :119-121 / :130-132
+      if (VEL) {
+        const float4 d = c_vel.v[it];
+        allegro_put4<OW, AD>(tile, envl, col, make_float4(p.vel_obs_scale * d.x, p.vel_obs_scale * d.y, p.vel_obs_scale * d.z,
+                                                          p.vel_obs_scale * d.w));  // :133
+      }
+      allegro_put4<OW, C_ACT>(tile, envl, col, c_act.v[it]);  // :128 / :144
+    }
+    // ---- C: the per-env block, one env per lane
+    const q4 rel = quat_mul(orot, quat_conjugate(grot));
+    float* r = tile + lane * OW + C_OBJ;
+    if (VEL) {  // :135-142
+      const float blk[24] = {opl.x, opl.y, opl.z, orot.w, orot.x, orot.y, orot.z, olin.x, olin.y, olin.z,
+                             p.vel_obs_scale * oang.x, p.vel_obs_scale * oang.y, p.vel_obs_scale * oang.z,
+                             gpos.x, gpos.y, gpos.z, grot.w, grot.x, grot.y, grot.z, rel.w, rel.x, rel.y, rel.z};
+#pragma unroll
+      for (int k = 0; k < 24; ++k) r[k] = blk[k];
+    } else {  // :123-127
+      const float blk[18] = {opl.x, opl.y, opl.z, orot.w, orot.x, orot.y, orot.z,
+                             gpos.x, gpos.y, gpos.z, grot.w, grot.x, grot.y, grot.z, rel.w, rel.x, rel.y, rel.z};
+#pragma unroll
+      for (int k = 0; k < 18; ++k) r[k] = blk[k];
+    }
+  }
+
+  if (do_progress) progress += 1;  // rl_task.py:289
+  if (do_metrics) {
+    const HandRewardOut o = hand_reward(a, opl, orot, gpos, grot, action_penalty, reset_in, reset_goal_in, progress, successes);
+    if (live) {
+      a.b.rew_buf[env] = o.reward;
+      a.b.reset_buf[env] = o.resets;
+      a.b.reset_goal_buf[env] = o.goal_resets;
+      a.b.progress_buf[env] = o.progress;
+      a.b.successes[env] = o.successes;
+      if (a.b.randomization_buf) a.b.randomization_buf[env] += 1;  // :297
+    }
+    const unsigned long long mr = __ballot(live && o.resets != 0), mg = __ballot(live && o.goal_resets != 0);
+    const float nres = wave_sum_f(live ? (float)o.resets : 0.f);
+    const float fin = wave_sum_f(live ? o.successes * (float)o.resets : 0.f);  // :523
+    if (lane == 0) {
+      a.b.reset_workspace[t] = __popcll(mr);
+      a.b.goal_workspace[t] = __popcll(mg);
+      a.b.reduce_workspace[2 * t + 0] = nres;
+      a.b.reduce_workspace[2 * t + 1] = fin;
+    }
+  } else if (do_progress && live) {
+    a.b.progress_buf[env] = progress;
+  }
+  __syncthreads();
+
+  // ---- D: tile -> HBM
+  if (do_obs) store_tile<OW, FULL>(tile, a.b.obs_buf + env0 * OW, nv * OW);
+}
+
+template <int OBS>
+__global__ __launch_bounds__(WAVE) void allegro_post_kernel(const HandPost a) {
+  __shared__ __align__(16) float tile[TILE * (OBS == OIGE_HAND_OBS_ALLEGRO_FULL ? 72 : 50)];
+  const int64_t t = blockIdx.x;
+  const int64_t left = a.n - t * TILE;
+  if (left >= TILE)
+    allegro_post_tile<OBS, true>(a, tile, t, TILE);
+  else
+    allegro_post_tile<OBS, false>(a, tile, t, (int)left);
+}
+
 // consecutive_successes update (:522-529): single workgroup, tile order
 __global__ __launch_bounds__(1024) void hand_finalize_kernel(const float* __restrict__ partials, int64_t tiles,
                                                              float* __restrict__ cons, float av, float one_minus_av) {
@@ -463,14 +622,15 @@ __device__ __forceinline__ void hand_reset_goal(const HandPre& a, int64_t i, int
 }
 
 // reset_idx (:397-441) for env i -> compacted row k
+template <int D>
 __device__ __forceinline__ void hand_reset_env(const HandPre& a, int64_t i, int64_t k) {
   const oige_hand_params& p = a.p;
-  float u[2 * HD + 5];
+  float u[2 * D + 5];
   if (a.r.u_reset) {
 #pragma unroll
-    for (int q = 0; q < 2 * HD + 5; ++q) u[q] = a.r.u_reset[k * (2 * HD + 5) + q];
+    for (int q = 0; q < 2 * D + 5; ++q) u[q] = a.r.u_reset[k * (2 * D + 5) + q];
   } else {
-    hand_draw<2 * HD + 5>(a.r, i, 1u, u);
+    hand_draw<2 * D + 5>(a.r, i, 1u, u);
   }
   hand_reset_goal(a, i, k, a.r.u_reset_goal, 2u, a.r.r_goal_world_pos_out, a.r.r_goal_rot_out);  // :401
   const float* oi = a.r.object_init_pos + i * 3;
@@ -482,16 +642,16 @@ __device__ __forceinline__ void hand_reset_env(const HandPre& a, int64_t i, int6
 #pragma unroll
   for (int c = 0; c < 6; ++c) a.r.object_vel_out[k * 6 + c] = 0.0f;  // :412-413
 #pragma unroll
-  for (int j = 0; j < HD; ++j) {
+  for (int j = 0; j < D; ++j) {
     const float delta_max = p.dof_upper[j] - p.dof_default_pos[j];
     const float delta_min = p.dof_lower[j] - p.dof_default_pos[j];
     const float rand_delta = delta_min + ((delta_max - delta_min) * 0.5f) * (u[5 + j] + 1.0f);  // :419
     const float pos = p.dof_default_pos[j] + p.reset_dof_pos_noise * rand_delta;                 // :421
-    const float vel = p.dof_default_vel[j] + p.reset_dof_vel_noise * u[5 + HD + j];             // :426-429
-    a.r.dof_pos_out[k * HD + j] = pos;
-    a.r.dof_vel_out[k * HD + j] = vel;
-    a.b.prev_targets[i * HD + j] = pos;  // :431-432
-    a.b.cur_targets[i * HD + j] = pos;
+    const float vel = p.dof_default_vel[j] + p.reset_dof_vel_noise * u[5 + D + j];             // :426-429
+    a.r.dof_pos_out[k * D + j] = pos;
+    a.r.dof_vel_out[k * D + j] = vel;
+    a.b.prev_targets[i * D + j] = pos;  // :431-432
+    a.b.cur_targets[i * D + j] = pos;
   }
   a.b.progress_buf[i] = 0;  // :439-441
   a.b.reset_buf[i] = 0;
@@ -540,11 +700,12 @@ __device__ __forceinline__ void hand_draw4_at(const oige_hand_reset_io& r, int64
 //   4. the LDS tile streams out as targets_out.
 // Every global access of phases 1, 3 and 4 is a 16-byte lane-linear one (the first version wrote prev/cur/targets with
 // per-env strided dword stores: 4x the algorithmic write traffic, 460 us at 1 M envs).
+template <int D, int A>
 __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
   __shared__ int lds_a[GROUP_TILES], lds_b[GROUP_TILES];
   __shared__ int s_list_r[GROUP], s_list_g[GROUP], s_rank[GROUP];
-  __shared__ int s_inv[HD];
-  __shared__ __align__(16) float s_act[GROUP * HA];
+  __shared__ int s_inv[D];
+  __shared__ __align__(16) float s_act[GROUP * A];
   const oige_hand_params& p = a.p;
   const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
@@ -555,7 +716,7 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
   const bool live = env < a.n;
   const bool f_env = live && a.b.reset_buf[env] != 0;
   const bool f_goal = live && a.b.reset_goal_buf[env] != 0;
-  if (tid < HD) s_inv[tid] = -1;
+  if (tid < D) s_inv[tid] = -1;
   const int64_t kg = group_rank(f_goal, off_g, g, lds_b);  // (barrier inside)
   const int64_t kr = group_rank(f_env, off_r, g, lds_a);
   const int32_t k0g = off_g[g], k0r = off_r[g];
@@ -563,15 +724,15 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
   if (f_goal) s_list_g[(int)(kg - k0g)] = tid;
   if (f_env) s_list_r[(int)(kr - k0r)] = tid;
   s_rank[tid] = f_env ? (int)(kr - k0r) : -1;
-  if (tid < HA) s_inv[p.actuated_dof_indices[tid]] = tid;
+  if (tid < A) s_inv[p.actuated_dof_indices[tid]] = tid;
 
   // ---- 1: actions -> (clamp) -> actions_out, LDS
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
   {
-    const int64_t base = g * GROUP * HA;
-    const int nf4 = (int)(envs_here * HA / 4);  // HA % 4 == 0
+    const int64_t base = g * GROUP * A;
+    const int nf4 = (int)(envs_here * A / 4);  // A % 4 == 0
 #pragma unroll
-    for (int it = 0; it < HA / 4; ++it) {
+    for (int it = 0; it < A / 4; ++it) {
       const int f = it * GROUP + tid;
       if (f < nf4) {
         float4 v = *reinterpret_cast<const float4*>(a.actions_in + base + 4 * f);
@@ -600,14 +761,14 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
   const float one_minus = p.one_minus_act_moving_average;
   const float speed_dt = p.dof_speed_scale_dt;
   {
-    const int64_t base = g * GROUP * HD;
-    const int nf4 = (int)(envs_here * HD / 4);  // HD % 4 == 0
+    const int64_t base = g * GROUP * D;
+    const int nf4 = (int)(envs_here * D / 4);  // D % 4 == 0
 #pragma unroll
-    for (int it = 0; it < HD / 4; ++it) {
+    for (int it = 0; it < D / 4; ++it) {
       const int f = it * GROUP + tid;
       if (f >= nf4) continue;
       const int e = 4 * f;
-      const int il = e / HD, j0 = e - il * HD;
+      const int il = e / D, j0 = e - il * D;
       const int64_t i = g * GROUP + il;
       const int lr = s_rank[il];
       int kk[4];
@@ -621,7 +782,7 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
       if (lr >= 0) {  // reset row: re-drawn DOF state (:415-436)
         float up[4], uv[4] = {0.f, 0.f, 0.f, 0.f};
         hand_draw4_at(a.r, i, 1u, 5 + j0, up);
-        if (p.reset_dof_vel_noise != 0.0f) hand_draw4_at(a.r, i, 1u, 5 + HD + j0, uv);
+        if (p.reset_dof_vel_noise != 0.0f) hand_draw4_at(a.r, i, 1u, 5 + D + j0, uv);
         float vel[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -633,7 +794,7 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
           vel[q] = p.dof_default_vel[j] + p.reset_dof_vel_noise * uv[q];                            // :426-429
           cur[q] = prev[q];                                                                          // :431-432
         }
-        const int64_t row = ((int64_t)k0r + lr) * HD + j0;
+        const int64_t row = ((int64_t)k0r + lr) * D + j0;
         *reinterpret_cast<float4*>(a.r.dof_pos_out + row) = make_float4(prev[0], prev[1], prev[2], prev[3]);
         *reinterpret_cast<float4*>(a.r.dof_vel_out + row) = make_float4(vel[0], vel[1], vel[2], vel[3]);
       } else {
@@ -651,7 +812,7 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
         if (kk[q] < 0) continue;
         const int j = j0 + q;
         const float lo = p.dof_lower[j], hi = p.dof_upper[j];
-        const float act = s_act[il * HA + kk[q]];
+        const float act = s_act[il * A + kk[q]];
         float c;
         if (p.use_relative_control) {
           c = tensor_clamp(prev[q] + speed_dt * act, lo, hi);  // :334-341
@@ -662,7 +823,7 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
         }
         cur[q] = c;
         prev[q] = c;  // :358
-        s_act[il * HA + kk[q]] = c;  // the action slot becomes the target slot (same thread reads and writes it)
+        s_act[il * A + kk[q]] = c;  // the action slot becomes the target slot (same thread reads and writes it)
       }
       *reinterpret_cast<float4*>(a.b.cur_targets + base + e) = make_float4(cur[0], cur[1], cur[2], cur[3]);
       *reinterpret_cast<float4*>(a.b.prev_targets + base + e) = make_float4(prev[0], prev[1], prev[2], prev[3]);
@@ -672,10 +833,10 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
 
   // ---- 4: targets_out = cur_targets[:, actuated] (:360-362)
   {
-    const int64_t base = g * GROUP * HA;
-    const int nf4 = (int)(envs_here * HA / 4);
+    const int64_t base = g * GROUP * A;
+    const int nf4 = (int)(envs_here * A / 4);
 #pragma unroll
-    for (int it = 0; it < HA / 4; ++it) {
+    for (int it = 0; it < A / 4; ++it) {
       const int f = it * GROUP + tid;
       if (f < nf4) *reinterpret_cast<float4*>(a.targets_out + base + 4 * f) = *reinterpret_cast<const float4*>(s_act + 4 * f);
     }
@@ -686,12 +847,13 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
   }
 }
 
+template <int D>
 __global__ __launch_bounds__(256) void hand_reset_idx_kernel(const HandPre a, int64_t max_ids) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= max_ids || k >= *a.r.count) return;
   const int64_t i = a.r.env_ids[k];
   if (i < 0 || i >= a.n) return;
-  hand_reset_env(a, i, k);
+  hand_reset_env<D>(a, i, k);
 }
 
 __global__ __launch_bounds__(256) void hand_reset_goal_kernel(const HandPre a, int64_t max_ids) {
@@ -703,12 +865,23 @@ __global__ __launch_bounds__(256) void hand_reset_goal_kernel(const HandPre a, i
 }
 
 // ---------------------------------------------------------------- host dispatch
+static bool is_allegro(const oige_hand_params* p) {
+  return p->obs_type == OIGE_HAND_OBS_ALLEGRO_FULL || p->obs_type == OIGE_HAND_OBS_ALLEGRO_FULL_NO_VEL;
+}
+
 static int check_hand(const oige_hand_params* p, const oige_hand_buffers* b, int64_t n) {
   OIGE_REQUIRE(p && b, "hand: null params/buffers");
   OIGE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) / 256, "hand: num_envs %lld out of range", (long long)n);
-  OIGE_REQUIRE(p->obs_type == OIGE_HAND_OBS_OPENAI || p->obs_type == OIGE_HAND_OBS_FULL,
-               "hand: observationType must be openai (0) or full (2); full_no_vel raises a shape error in the reference "
-               "(shadow_hand.py:190) and non-asymmetric full_state is dead code there (shadow_hand.py:263-306)");
+  OIGE_REQUIRE(p->obs_type == OIGE_HAND_OBS_OPENAI || p->obs_type == OIGE_HAND_OBS_FULL || is_allegro(p),
+               "hand: observationType must be openai (0) / full (2) for ShadowHand or allegro full_no_vel (3) / full (4); "
+               "ShadowHand full_no_vel raises a shape error in the reference (shadow_hand.py:190) and non-asymmetric "
+               "full_state is dead code there (shadow_hand.py:263-306)");
+  if (is_allegro(p)) {
+    OIGE_REQUIRE(!p->asymmetric_obs, "hand: AllegroHand has no states (allegro_hand.py:71)");
+    for (int k = 0; k < OIGE_ALLEGRO_DOFS; ++k)
+      OIGE_REQUIRE(p->actuated_dof_indices[k] == k, "hand: AllegroHand actuates all 16 DOFs in order (allegro_hand_view.py:53)");
+    return OIGE_OK;
+  }
   for (int k = 0; k < OIGE_HAND_ACTIONS; ++k)
     OIGE_REQUIRE(p->actuated_dof_indices[k] >= 0 && p->actuated_dof_indices[k] < OIGE_HAND_DOFS &&
                      (k == 0 || p->actuated_dof_indices[k] > p->actuated_dof_indices[k - 1]),
@@ -731,6 +904,14 @@ static int launch_hand_post(const HandPost& a, hipStream_t s) {
   return check_launch("hand_post_kernel");
 }
 
+static int finalize_hand(const HandPost& a, hipStream_t s) {
+  if (!(a.stages & OIGE_STAGE_METRICS)) return OIGE_OK;
+  const float av = a.p.av_factor;  // reaches the jit function as float(fp32 tensor) (:59,:293)
+  hipLaunchKernelGGL(hand_finalize_kernel, dim3(1), dim3(1024), 0, s, a.b.reduce_workspace, num_tiles(a.n),
+                     a.b.consecutive_successes, av, (float)(1.0 - (double)av));
+  return check_launch("hand_finalize_kernel");
+}
+
 }  // namespace oige
 
 using namespace oige;
@@ -751,20 +932,6 @@ int oige_hand_post_physics(const oige_hand_params* params, const oige_hand_state
                "hand_post_physics: null object/goal/actions/progress pointer");
   OIGE_REQUIRE(aligned16(st.object_rot) && aligned16(b.goal_rot) && aligned16(b.actions),
                "hand_post_physics: object_rot/goal_rot/actions must be 16-byte aligned");
-  if (stages & OIGE_STAGE_OBS) {
-    OIGE_REQUIRE(b.obs_buf && aligned16(b.obs_buf), "hand_post_physics: obs_buf null or unaligned");
-    OIGE_REQUIRE(st.object_velocities && st.fingertip_pos && aligned16(st.fingertip_pos) &&
-                     (reinterpret_cast<uintptr_t>(st.object_velocities) & 7u) == 0,
-                 "hand_post_physics: null/unaligned object_velocities or fingertip_pos");
-    if (asym || params->obs_type == OIGE_HAND_OBS_FULL)
-      OIGE_REQUIRE(st.fingertip_rot && st.fingertip_velocities && st.hand_dof_pos && st.hand_dof_vel &&
-                       aligned16(st.fingertip_rot) && aligned16(st.fingertip_velocities) && aligned16(st.hand_dof_pos) &&
-                       aligned16(st.hand_dof_vel),
-                   "hand_post_physics: null/unaligned fingertip or hand dof state");
-    if (asym)
-      OIGE_REQUIRE(b.states_buf && st.vec_sensor && aligned16(b.states_buf) && aligned16(st.vec_sensor),
-                   "hand_post_physics: asymmetric_obs needs states_buf and vec_sensor (16-byte aligned)");
-  }
   if (stages & OIGE_STAGE_METRICS)
     OIGE_REQUIRE(b.rew_buf && b.reset_buf && b.reset_goal_buf && b.successes && b.consecutive_successes &&
                      b.reset_workspace && b.goal_workspace && b.reduce_workspace,
@@ -779,18 +946,44 @@ int oige_hand_post_physics(const oige_hand_params* params, const oige_hand_state
   a.half_fall_penalty = (float)(0.5 * (double)params->fall_penalty);
   hipStream_t s = (hipStream_t)stream;
   int rc;
+  if (is_allegro(params)) {
+    if (stages & OIGE_STAGE_OBS) {
+      OIGE_REQUIRE(b.obs_buf && aligned16(b.obs_buf), "hand_post_physics: obs_buf null or unaligned");
+      OIGE_REQUIRE(st.hand_dof_pos && aligned16(st.hand_dof_pos), "hand_post_physics: null/unaligned hand_dof_pos");
+      if (params->obs_type == OIGE_HAND_OBS_ALLEGRO_FULL)
+        OIGE_REQUIRE(st.hand_dof_vel && aligned16(st.hand_dof_vel) && st.object_velocities &&
+                         (reinterpret_cast<uintptr_t>(st.object_velocities) & 7u) == 0,
+                     "hand_post_physics: null/unaligned hand_dof_vel or object_velocities");
+    }
+    const unsigned tiles = (unsigned)num_tiles(num_envs);
+    if (params->obs_type == OIGE_HAND_OBS_ALLEGRO_FULL)
+      hipLaunchKernelGGL((allegro_post_kernel<OIGE_HAND_OBS_ALLEGRO_FULL>), dim3(tiles), dim3(WAVE), 0, s, a);
+    else
+      hipLaunchKernelGGL((allegro_post_kernel<OIGE_HAND_OBS_ALLEGRO_FULL_NO_VEL>), dim3(tiles), dim3(WAVE), 0, s, a);
+    rc = check_launch("allegro_post_kernel");
+    if (rc) return rc;
+    return finalize_hand(a, s);
+  }
+  if (stages & OIGE_STAGE_OBS) {
+    OIGE_REQUIRE(b.obs_buf && aligned16(b.obs_buf), "hand_post_physics: obs_buf null or unaligned");
+    OIGE_REQUIRE(st.object_velocities && st.fingertip_pos && aligned16(st.fingertip_pos) &&
+                     (reinterpret_cast<uintptr_t>(st.object_velocities) & 7u) == 0,
+                 "hand_post_physics: null/unaligned object_velocities or fingertip_pos");
+    if (asym || params->obs_type == OIGE_HAND_OBS_FULL)
+      OIGE_REQUIRE(st.fingertip_rot && st.fingertip_velocities && st.hand_dof_pos && st.hand_dof_vel &&
+                       aligned16(st.fingertip_rot) && aligned16(st.fingertip_velocities) && aligned16(st.hand_dof_pos) &&
+                       aligned16(st.hand_dof_vel),
+                   "hand_post_physics: null/unaligned fingertip or hand dof state");
+    if (asym)
+      OIGE_REQUIRE(b.states_buf && st.vec_sensor && aligned16(b.states_buf) && aligned16(st.vec_sensor),
+                   "hand_post_physics: asymmetric_obs needs states_buf and vec_sensor (16-byte aligned)");
+  }
   if (params->obs_type == OIGE_HAND_OBS_OPENAI)
     rc = asym ? launch_hand_post<OIGE_HAND_OBS_OPENAI, true>(a, s) : launch_hand_post<OIGE_HAND_OBS_OPENAI, false>(a, s);
   else
     rc = asym ? launch_hand_post<OIGE_HAND_OBS_FULL, true>(a, s) : launch_hand_post<OIGE_HAND_OBS_FULL, false>(a, s);
   if (rc) return rc;
-  if (stages & OIGE_STAGE_METRICS) {
-    const float av = params->av_factor;  // reaches the jit function as float(fp32 tensor) (:59,:293)
-    hipLaunchKernelGGL(hand_finalize_kernel, dim3(1), dim3(1024), 0, s, b.reduce_workspace, num_tiles(num_envs),
-                       b.consecutive_successes, av, (float)(1.0 - (double)av));
-    return check_launch("hand_finalize_kernel");
-  }
-  return OIGE_OK;
+  return finalize_hand(a, s);
 }
 
 static int fill_pre(HandPre& a, const oige_hand_params* params, const oige_hand_buffers* buffers,
@@ -848,7 +1041,10 @@ int oige_hand_pre_physics(const oige_hand_params* params, const float* actions_i
   }
   if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
   if (int rc = launch_scan_groups(num_envs, a.b.goal_workspace, s)) return rc;
-  hipLaunchKernelGGL(hand_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  if (is_allegro(params))
+    hipLaunchKernelGGL((hand_pre_kernel<OIGE_ALLEGRO_DOFS, OIGE_ALLEGRO_DOFS>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  else
+    hipLaunchKernelGGL((hand_pre_kernel<OIGE_HAND_DOFS, OIGE_HAND_ACTIONS>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
   return check_launch("hand_pre_kernel");
 }
 
@@ -864,7 +1060,11 @@ int oige_hand_reset_idx(const oige_hand_params* params, const oige_hand_buffers*
   OIGE_REQUIRE((r.u_reset == nullptr) == (r.u_reset_goal == nullptr), "hand_reset_idx: pass both u_reset and u_reset_goal or neither");
   OIGE_REQUIRE(aligned16(r.r_goal_rot_out) && aligned16(r.object_rot_out), "hand_reset_idx: (n,4) outputs must be 16-byte aligned");
   if (max_ids == 0) return OIGE_OK;
-  hipLaunchKernelGGL(hand_reset_idx_kernel, dim3((unsigned)((max_ids + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, max_ids);
+  const dim3 grid((unsigned)((max_ids + 255) / 256));
+  if (is_allegro(params))
+    hipLaunchKernelGGL(hand_reset_idx_kernel<OIGE_ALLEGRO_DOFS>, grid, dim3(256), 0, (hipStream_t)stream, a, max_ids);
+  else
+    hipLaunchKernelGGL(hand_reset_idx_kernel<OIGE_HAND_DOFS>, grid, dim3(256), 0, (hipStream_t)stream, a, max_ids);
   return check_launch("hand_reset_idx_kernel");
 }
 

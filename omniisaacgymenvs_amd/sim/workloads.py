@@ -76,11 +76,11 @@ def load_locomotion_state(task, st: Dict[str, Tensor]) -> None:
 
 
 def hand_state(n: int, env_pos: Tensor, goal_pos_local: Tensor, lower: Tensor, upper: Tensor, device="cpu",
-               seed: int = 1234) -> Dict[str, Tensor]:
+               seed: int = 1234, num_actions: int = 20, fingertips: int = 5) -> Dict[str, Tensor]:
     """C4: object near the goal (N(0,0.1) -> ~2 % beyond fallDistance 0.24), unit
     quaternions with 5 % of the objects exactly at the goal rotation (successes), fingertip state
     N(0,1), dof_pos in U(lo,hi), sensors N(0,1), actions U(-1,1), successes randint(0,50),
-    progress randint(0,160)."""
+    progress randint(0,160).  AllegroHand: ``num_actions=16, fingertips=0`` (no fingertip / sensor arrays)."""
     g = _gen(device, seed)
     f = dict(device=device, dtype=torch.float32, generator=g)
     env_pos, goal_pos_local = env_pos.to(device), goal_pos_local.to(device)
@@ -95,15 +95,16 @@ def hand_state(n: int, env_pos: Tensor, goal_pos_local: Tensor, lower: Tensor, u
     same = torch.rand(n, **f) < 0.05
     object_rot = torch.where(same.unsqueeze(-1), goal_rot, object_rot).contiguous()
     object_pos = (goal_pos_local + torch.randn(n, 3, **f) * 0.1 + env_pos).contiguous()
+    nf = fingertips
     return dict(
         object_pos=object_pos, object_rot=object_rot, object_vel=torch.randn(n, 6, **f),
         goal_rot=goal_rot,
-        ft_pos=(torch.randn(n * 5, 3, **f) + env_pos.repeat_interleave(5, dim=0)).contiguous(),
-        ft_rot=quat(n * 5), ft_vel=torch.randn(n * 5, 6, **f),
+        ft_pos=(torch.randn(n * nf, 3, **f) + env_pos.repeat_interleave(nf, dim=0)).contiguous(),
+        ft_rot=quat(n * nf), ft_vel=torch.randn(n * nf, 6, **f),
         dof_pos=(lower + torch.rand(n, lower.shape[0], **f) * (upper - lower)).contiguous(),
         dof_vel=torch.randn(n, lower.shape[0], **f),
-        sensors=torch.randn(n, 5, 6, **f),
-        actions=torch.rand(n, 20, **f) * 2.0 - 1.0,
+        sensors=torch.randn(n, nf, 6, **f),
+        actions=torch.rand(n, num_actions, **f) * 2.0 - 1.0,
         successes=torch.randint(0, 50, (n,), device=device, generator=g).float(),
         progress=torch.randint(0, 160, (n,), device=device, generator=g, dtype=torch.int64),
         reset=(torch.rand(n, **f) < 0.02).long(),
@@ -117,13 +118,14 @@ def load_hand_state(task, st: Dict[str, Tensor]) -> None:
     task._objects.orientations.copy_(st["object_rot"].to(dev))
     task._objects.velocities.copy_(st["object_vel"].to(dev))
     task.goal_rot.copy_(st["goal_rot"].to(dev))
-    fingers = task._hands._fingers
-    fingers.positions.copy_(st["ft_pos"].to(dev))
-    fingers.orientations.copy_(st["ft_rot"].to(dev))
-    fingers.velocities.copy_(st["ft_vel"].to(dev))
+    if task.num_fingertips > 0:
+        fingers = task._hands._fingers
+        fingers.positions.copy_(st["ft_pos"].to(dev))
+        fingers.orientations.copy_(st["ft_rot"].to(dev))
+        fingers.velocities.copy_(st["ft_vel"].to(dev))
+        task._hands.measured_joint_forces.copy_(st["sensors"].to(dev))
     task._hands.joint_positions.copy_(st["dof_pos"].to(dev))
     task._hands.joint_velocities.copy_(st["dof_vel"].to(dev))
-    task._hands.measured_joint_forces.copy_(st["sensors"].to(dev))
     task.actions.copy_(st["actions"].to(dev))
     task.successes.copy_(st["successes"].to(dev))
     task.progress_buf.copy_(st["progress"].to(dev))

@@ -1,6 +1,6 @@
 """InHandManipulationTask -- host-side mirror of the reference class
 (/root/reference/omniisaacgymenvs/tasks/shared/in_hand_manipulation.py:43-441) whose arithmetic runs
-in liboige_hip.so (csrc/hand.hip).  Same method names and buffer contract:
+in liboige_hip.so (csrc/hand.hip); base of ShadowHandTask and AllegroHandTask.  Same method names and buffer contract:
 ``calculate_metrics / pre_physics_step / is_done / reset_target_pose / reset_idx / post_reset``
 plus a fused ``post_physics_step``.  No torch/CPU fallback.
 
@@ -20,6 +20,7 @@ from ... import _lib
 from ..base.rl_task import RLTask
 
 _OBS_TYPES = {"openai": _lib.HAND_OBS_OPENAI, "full": _lib.HAND_OBS_FULL}
+_ALLEGRO_OBS_TYPES = {"full_no_vel": _lib.HAND_OBS_ALLEGRO_FULL_NO_VEL, "full": _lib.HAND_OBS_ALLEGRO_FULL}
 
 
 class InHandManipulationTask(RLTask):
@@ -112,12 +113,13 @@ class InHandManipulationTask(RLTask):
 
     # ------------------------------------------------------------------ C-ABI argument blocks
     def _params(self) -> _lib.HandParams:
-        if self.obs_type not in _OBS_TYPES:
+        obs_types = _ALLEGRO_OBS_TYPES if self.num_fingertips == 0 else _OBS_TYPES  # AllegroHand has no fingertip bodies
+        if self.obs_type not in obs_types:
             raise _lib.OigeError(
                 f"observationType {self.obs_type!r}: full_no_vel raises a shape error in the reference "
                 "(shadow_hand.py:190) and non-asymmetric full_state is dead code there (shadow_hand.py:263-306)")
         p = _lib.HandParams()
-        p.obs_type = _OBS_TYPES[self.obs_type]
+        p.obs_type = obs_types[self.obs_type]
         p.asymmetric_obs = int(bool(self.asymmetric_obs))
         p.max_consecutive_successes = int(self.max_consecutive_successes)
         p.use_relative_control = int(bool(self.use_relative_control))
@@ -199,26 +201,28 @@ class InHandManipulationTask(RLTask):
         n, nf, nd = self._num_envs, self.num_fingertips, self.num_hand_dofs
         object_pos, object_rot = self._objects.get_world_poses(clone=False)
         object_velocities = self._objects.get_velocities(clone=False)
-        fingertip_pos, fingertip_rot = self._hands._fingers.get_world_poses(clone=False)
-        fingertip_velocities = self._hands._fingers.get_velocities(clone=False)
         hand_dof_pos = self._hands.get_joint_positions(clone=False)
         hand_dof_vel = self._hands.get_joint_velocities(clone=False)
         rq = _lib.require_device_tensor
         rq(object_pos, torch.float32, (n, 3), "object_pos")
         rq(object_rot, torch.float32, (n, 4), "object_rot")
         rq(object_velocities, torch.float32, (n, 6), "object_velocities")
-        rq(fingertip_pos, torch.float32, (n * nf, 3), "fingertip_pos")
-        rq(fingertip_rot, torch.float32, (n * nf, 4), "fingertip_rot")
-        rq(fingertip_velocities, torch.float32, (n * nf, 6), "fingertip_velocities")
         rq(hand_dof_pos, torch.float32, (n, nd), "hand_dof_pos")
         rq(hand_dof_vel, torch.float32, (n, nd), "hand_dof_vel")
         rq(self._env_pos, torch.float32, (n, 3), "_env_pos")
         s = _lib.HandState()
         s.object_pos, s.object_rot, s.object_velocities = object_pos.data_ptr(), object_rot.data_ptr(), object_velocities.data_ptr()
-        s.fingertip_pos, s.fingertip_rot = fingertip_pos.data_ptr(), fingertip_rot.data_ptr()
-        s.fingertip_velocities = fingertip_velocities.data_ptr()
         s.hand_dof_pos, s.hand_dof_vel = hand_dof_pos.data_ptr(), hand_dof_vel.data_ptr()
-        keep = [object_pos, object_rot, object_velocities, fingertip_pos, fingertip_rot, fingertip_velocities, hand_dof_pos, hand_dof_vel]
+        keep = [object_pos, object_rot, object_velocities, hand_dof_pos, hand_dof_vel]
+        if nf > 0:  # shadow_hand.py:123-127
+            fingertip_pos, fingertip_rot = self._hands._fingers.get_world_poses(clone=False)
+            fingertip_velocities = self._hands._fingers.get_velocities(clone=False)
+            rq(fingertip_pos, torch.float32, (n * nf, 3), "fingertip_pos")
+            rq(fingertip_rot, torch.float32, (n * nf, 4), "fingertip_rot")
+            rq(fingertip_velocities, torch.float32, (n * nf, 6), "fingertip_velocities")
+            s.fingertip_pos, s.fingertip_rot = fingertip_pos.data_ptr(), fingertip_rot.data_ptr()
+            s.fingertip_velocities = fingertip_velocities.data_ptr()
+            keep += [fingertip_pos, fingertip_rot, fingertip_velocities]
         if self.obs_type == "full_state" or self.asymmetric_obs:
             vec_sensor = self._hands.get_measured_joint_forces(joint_indices=self._hands._sensor_indices)
             rq(vec_sensor, torch.float32, (n, nf, 6), "vec_sensor_tensor")

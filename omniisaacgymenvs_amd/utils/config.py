@@ -112,6 +112,12 @@ _OPENAI_FF_ENV.update({
 TASK_DEFAULTS["ShadowHandOpenAI_FF"] = {"name": "ShadowHand", "env": _OPENAI_FF_ENV, "sim": dict(_SIM),
                                        "domain_randomization": copy.deepcopy(_SHADOW_HAND_DR)}
 
+# cfg/task/AllegroHand.yaml:7-42 (no asymmetric observations, no force perturbation keys, no domain_randomization section)
+_ALLEGRO_HAND_ENV = {k: v for k, v in _SHADOW_HAND_ENV.items()
+                     if k not in ("forceScale", "forceProbRange", "forceDecay", "forceDecayInterval", "asymmetric_observations")}
+_ALLEGRO_HAND_ENV.update({"controlFrequencyInv": 4})
+TASK_DEFAULTS["AllegroHand"] = {"name": "AllegroHand", "env": _ALLEGRO_HAND_ENV, "sim": dict(_SIM, dt=0.0083)}
+
 # cfg/task/AnymalTerrain.yaml:5-103
 TASK_DEFAULTS["AnymalTerrain"] = {
     "name": "AnymalTerrain",
