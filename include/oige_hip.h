@@ -383,7 +383,8 @@ typedef struct oige_anymal_buffers {
   float* env_origins;        /* (N,3) */
   float* extras;             /* (14,) device: 13 x rew_<key> means / max_episode_length_s, terrain_level mean (:361-367) */
   int32_t* reset_workspace;  /* oige_workspace_ints(N) */
-  float* reduce_workspace;   /* 16 * oige_num_tiles(N) + 4 floats */
+  float* reduce_workspace;   /* (16 + 512) * oige_num_tiles(N) + 4 floats, 16-byte aligned: per-tile partial sums, then
+                                the 8-float pose record per env that the head kernel hands to the scan kernel */
 } oige_anymal_buffers;
 
 /* reset rows for the view setters (:334-339), compacted in ascending env order */

@@ -129,63 +129,77 @@ __global__ __launch_bounds__(1024) void anymal_command_norm_kernel(float* __rest
 }
 
 // ------------------------------------------------------------------ main
+// LDS row of one env in the head kernel: the 36 head columns of the observation and the 12 action columns (obs
+// 176:188), padded to 13 float4 (odd: per-lane 16-byte row accesses are bank-conflict free).  last_actions,
+// last_dof_vel and torques only feed three sums: each lane reads its own 48-byte rows of those straight from global.
+// The 140 height-scan columns never touch this tile: the scan kernel writes them.
+constexpr int ARW = 52;
+constexpr int L_DPOS = 12, L_DVEL = 24, L_ACT = 36;
+constexpr int AP4 = AP / 4;  // 35 float4 of scan columns per env
+// Pose record the head kernel leaves per env for the scan kernel, after the RW * tiles + 4 reduction floats of
+// reduce_workspace: (yaw quat w, z, base x, y), (base z - 0.5, -, -, -).  (Routing the 48 head / action columns through
+// the record too, so that the scan kernel writes whole 752-byte rows, was measured slower: 82 + 121 us against 79 + 99.)
+constexpr int APOSE = 8;
+__host__ __device__ inline int64_t pose_offset(int64_t tiles) { return tiles * RW + 4; }
+
+// RN(x / h) from inv = RN(1 / h): q0 = x inv, then two fma residual corrections.  The second one starts from a
+// faithful quotient and a correctly rounded reciprocal, which makes its result the correctly rounded quotient
+// (Markstein), i.e. bit-identical to the IEEE division torch performs (:586-593) for every finite in-range x;
+// tests/test_helpers_known_answers.py replays the sequence against true division.
+__device__ __forceinline__ float div_by_const(float x, float h, float inv) {
+  const float q0 = x * inv;
+  const float q1 = __builtin_fmaf(__builtin_fmaf(-q0, h, x), inv, q0);
+  return __builtin_fmaf(__builtin_fmaf(-q1, h, x), inv, q1);
+}
+
+__device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// uniform noise of four consecutive observation columns starting at flat float offset `off` (:438-439)
+__device__ __forceinline__ void anymal_noise4(const oige_anymal_reset_io& r, int64_t off, float (&uu)[4]) {
+  if (r.noise_u) {
+    const float4 t4 = *reinterpret_cast<const float4*>(r.noise_u + off);
+    uu[0] = t4.x; uu[1] = t4.y; uu[2] = t4.z; uu[3] = t4.w;
+  } else {
+    const int64_t gf = off / 4;
+    const u4 cc{(uint32_t)gf, (uint32_t)(gf >> 32) | (3u << 16), (uint32_t)r.step, (uint32_t)(r.step >> 32)};
+    const u4 x = philox4x32_10(cc, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
+    uu[0] = u01(x.x); uu[1] = u01(x.y); uu[2] = u01(x.z); uu[3] = u01(x.w);
+  }
+}
+
 template <bool FULLTILE>
-__device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __restrict__ lds, int64_t t, int nv) {
-  float* obs_t = lds;                       // 64 x 188
-  float* s_pose = lds + TILE * AO;           // 64 x float4: normalised yaw quat (w, z), base pos (x, y)
-  float* s_pz = s_pose + TILE * 4;           // 64: base z - 0.5
-  float* s_hx = s_pz + TILE;                 // 140 + 140: the scan grid (:173-187)
-  float* s_hy = s_hx + AP;
-  float* s_ns = s_hy + AP;                   // 188: noise_scale_vec (:157-171)
+__device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __restrict__ lds, int64_t t, int nv) {
+  float* rows = lds;                         // 64 x 52
+  float* s_ns = lds + TILE * ARW;            // 48: noise_scale_vec (:157-171) by LDS column (head 0:36, actions 36:48)
   const oige_anymal_params& p = a.p;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x;               // one wavefront per tile
   const int64_t env0 = t * TILE;
   const int64_t T = num_tiles(a.n);
-  constexpr int C_DPOS = 12, C_DVEL = 24, C_ACT = 176, C_LA = 36, C_LDV = 48, C_TQ = 60;  // scratch in the scan columns
+  float* pose_out = a.b.reduce_workspace + pose_offset(T) + env0 * APOSE;
 
   const bool step = a.mode == 0;
-  // ---- A/B: the six 12-wide arrays, lane-linear, into tile columns
+  // ---- A/B: the six 12-wide arrays, lane-linear, into row columns (12 % 4 == 0: a float4 never straddles rows)
   if (step) {
-    WgChunk<AD, ANT> c0, c1, c2, c3, c4, c5;
-    wg_load_chunk<AD, ANT, FULLTILE>(c0, a.s.dof_pos + env0 * AD, nv * AD);
-    wg_load_chunk<AD, ANT, FULLTILE>(c1, a.s.dof_vel + env0 * AD, nv * AD);
-    wg_load_chunk<AD, ANT, FULLTILE>(c2, a.b.actions + env0 * AD, nv * AD);
-    wg_load_chunk<AD, ANT, FULLTILE>(c3, a.b.last_actions + env0 * AD, nv * AD);
-    wg_load_chunk<AD, ANT, FULLTILE>(c4, a.b.last_dof_vel + env0 * AD, nv * AD);
-    wg_load_chunk<AD, ANT, FULLTILE>(c5, a.b.torques + env0 * AD, nv * AD);
-    wg_for_each<AD, ANT>(c0, [&](int e, int c, float v) { obs_t[e * AO + C_DPOS + c] = v; });
-    wg_for_each<AD, ANT>(c1, [&](int e, int c, float v) { obs_t[e * AO + C_DVEL + c] = v; });
-    wg_for_each<AD, ANT>(c2, [&](int e, int c, float v) { obs_t[e * AO + C_ACT + c] = v; });
-    wg_for_each<AD, ANT>(c3, [&](int e, int c, float v) { obs_t[e * AO + C_LA + c] = v; });
-    wg_for_each<AD, ANT>(c4, [&](int e, int c, float v) { obs_t[e * AO + C_LDV + c] = v; });
-    wg_for_each<AD, ANT>(c5, [&](int e, int c, float v) { obs_t[e * AO + C_TQ + c] = v; });
-  }
-  if (step) {
-    if (tid < AP) {  // meshgrid(x, y, indexing='ij') flattened: k = ix * 10 + iy
-      const int ix = tid / 10, iy = tid % 10;
-      s_hx[tid] = 0.1f * (float)(ix < 7 ? ix - 8 : ix - 5);  // :178-180
-      s_hy[tid] = 0.1f * (float)(iy < 5 ? iy - 5 : iy - 4);  // :175-177
-    }
-    if (tid < AO) {
+    Chunk<AD> c0, c1, c2;
+    load_chunk<AD, FULLTILE>(c0, a.s.dof_pos + env0 * AD, nv * AD);
+    load_chunk<AD, FULLTILE>(c1, a.s.dof_vel + env0 * AD, nv * AD);
+    load_chunk<AD, FULLTILE>(c2, a.b.actions + env0 * AD, nv * AD);
+    scatter_chunk<AD, ARW, L_DPOS, false>(c0, rows, 1.0f);
+    scatter_chunk<AD, ARW, L_DVEL, false>(c1, rows, 1.0f);
+    scatter_chunk<AD, ARW, L_ACT, false>(c2, rows, 1.0f);
+    if (tid < 48) {
       const int col = tid;
-      s_ns[tid] = col < 3 ? p.noise_scales[0] : col < 6 ? p.noise_scales[1] : col < 9 ? p.noise_scales[2]
-                : col < 12 ? 0.0f : col < 24 ? p.noise_scales[3] : col < 36 ? p.noise_scales[4]
-                : col < 176 ? p.noise_scales[5] : 0.0f;
+      s_ns[col] = col < 3 ? p.noise_scales[0] : col < 6 ? p.noise_scales[1] : col < 9 ? p.noise_scales[2]
+                : col < 12 ? 0.0f : col < 24 ? p.noise_scales[3] : col < 36 ? p.noise_scales[4] : 0.0f;
     }
   }
   __syncthreads();
 
-  // ---- C: per-env math, one env per lane of wave 0
-  if (tid < TILE) {
+  // ---- C: per-env math, one env per lane
+  {
     const bool live = FULLTILE || tid < nv;
     const int64_t env = live ? env0 + tid : env0;  // dead lanes shadow env0, never store
-    float* row = obs_t + tid * AO;
-    float dp[AD], dv[AD], act[AD], la[AD], ldv[AD], tq[AD];
-#pragma unroll
-    for (int j = 0; j < AD; ++j) {
-      dp[j] = row[C_DPOS + j]; dv[j] = row[C_DVEL + j]; act[j] = row[C_ACT + j];
-      la[j] = row[C_LA + j]; ldv[j] = row[C_LDV + j]; tq[j] = row[C_TQ + j];
-    }
+    float* row = rows + tid * ARW;
     const float* bp3 = a.s.base_pos + env * 3;
     f3 bpos{bp3[0], bp3[1], bp3[2]};
     const float4 q4v = *reinterpret_cast<const float4*>(a.s.base_quat + env * 4);
@@ -201,10 +215,6 @@ __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __r
     const bool has_fallen = step && a.b.has_fallen[env] != 0;
     const int64_t timeout = step ? a.b.timeout_buf[env] : 0;
 
-    if (!step) {
-#pragma unroll
-      for (int j = 0; j < AD; ++j) { dp[j] = 0.f; dv[j] = 0.f; act[j] = 0.f; la[j] = 0.f; ldv[j] = 0.f; tq[j] = 0.f; }
-    }
     // frame quantities (:422-427)
     const f3 lin = quat_rotate_inverse(bq, f3{v0.x, v0.y, v1.x});
     const f3 ang = quat_rotate_inverse(bq, f3{v1.y, v2.x, v2.y});
@@ -230,16 +240,42 @@ __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __r
     const float bh = bpos.z - 0.52f;
     const float rew_base_height = (bh * bh) * rs[OIGE_AR_BASE_HEIGHT];
     float s_tq = 0.f, s_acc = 0.f, s_rate = 0.f, s_hip = 0.f;
+    if (step) {  // the 12-wide sums, four columns at a time (sequential order j = 0..11)
+      const float4* tq_row = reinterpret_cast<const float4*>(a.b.torques + env * AD);
+      const float4* ldv_row = reinterpret_cast<const float4*>(a.b.last_dof_vel + env * AD);
+      const float4* la_row = reinterpret_cast<const float4*>(a.b.last_actions + env * AD);
+      float4 tq3[3], ldv3[3], la3[3];
 #pragma unroll
-    for (int j = 0; j < AD; ++j) {
-      const float t2 = tq[j] * tq[j];
-      const float d1 = ldv[j] - dv[j], d2 = la[j] - act[j];
-      s_tq = j == 0 ? t2 : s_tq + t2;
-      s_acc = j == 0 ? d1 * d1 : s_acc + d1 * d1;
-      s_rate = j == 0 ? d2 * d2 : s_rate + d2 * d2;
-      if (j < 4) {
-        const float h = __builtin_fabsf(dp[j] - p.default_dof_pos[j]);
-        s_hip = j == 0 ? h : s_hip + h;
+      for (int g = 0; g < AD / 4; ++g) { tq3[g] = tq_row[g]; ldv3[g] = ldv_row[g]; la3[g] = la_row[g]; }
+#pragma unroll
+      for (int g = 0; g < AD / 4; ++g) {
+        const float4 tq = tq3[g], ldv = ldv3[g], dv = lds4(row + L_DVEL + 4 * g);
+        const float4 la = la3[g], act = lds4(row + L_ACT + 4 * g);
+        const float tqv[4] = {tq.x, tq.y, tq.z, tq.w};
+        const float d1[4] = {ldv.x - dv.x, ldv.y - dv.y, ldv.z - dv.z, ldv.w - dv.w};
+        const float d2[4] = {la.x - act.x, la.y - act.y, la.z - act.z, la.w - act.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool first = g == 0 && q == 0;
+          s_tq = first ? tqv[q] * tqv[q] : s_tq + tqv[q] * tqv[q];
+          s_acc = first ? d1[q] * d1[q] : s_acc + d1[q] * d1[q];
+          s_rate = first ? d2[q] * d2[q] : s_rate + d2[q] * d2[q];
+        }
+        if (g == 0) {
+          const float4 dp = lds4(row + L_DPOS);
+          const float dpv[4] = {dp.x, dp.y, dp.z, dp.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float h = __builtin_fabsf(dpv[q] - p.default_dof_pos[q]);
+            s_hip = q == 0 ? h : s_hip + h;
+          }
+        }
+      }
+    } else {  // standalone reset_idx: all rows read as zero
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float h = __builtin_fabsf(0.0f - p.default_dof_pos[q]);
+        s_hip = q == 0 ? h : s_hip + h;
       }
     }
     const float rew_torque = s_tq * rs[OIGE_AR_TORQUE];
@@ -260,9 +296,9 @@ __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __r
 #pragma unroll
       for (int k = 0; k < AE; ++k) es[k] = a.b.episode_sums[(int64_t)k * a.n + env];
       if (step) {
-      es[0] += rew_lin_vel_xy; es[2] += rew_ang_vel_z; es[1] += rew_lin_vel_z; es[3] += rew_ang_vel_xy;
-      es[4] += rew_orient; es[5] += rew_torque; es[6] += rew_joint_acc; es[11] += rew_action_rate;
-      es[7] += rew_base_height; es[12] += rew_hip;
+        es[0] += rew_lin_vel_xy; es[2] += rew_ang_vel_z; es[1] += rew_lin_vel_z; es[3] += rew_ang_vel_xy;
+        es[4] += rew_orient; es[5] += rew_torque; es[6] += rew_joint_acc; es[11] += rew_action_rate;
+        es[7] += rew_base_height; es[12] += rew_hip;
       }
     } else {
 #pragma unroll
@@ -281,31 +317,50 @@ __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __r
       int64_t k = group_offsets[g];
       for (int64_t tt = g * GROUP_TILES; tt < t; ++tt) k += tile_counts[tt];
       k += rank_below(rmask);
-      float u[29];
-      if (a.r.u_dof_offset) {
-#pragma unroll
-        for (int j = 0; j < AD; ++j) {
-          u[j] = a.r.u_dof_offset[k * AD + j];
-          u[AD + j] = a.r.u_dof_vel[k * AD + j];
-        }
-        u[24] = a.r.u_xy[k * 2]; u[25] = a.r.u_xy[k * 2 + 1];
-        u[26] = a.r.u_cmd[k * 3]; u[27] = a.r.u_cmd[k * 3 + 1]; u[28] = a.r.u_cmd[k * 3 + 2];
-      } else {
-#pragma unroll
-        for (int blk = 0; blk < 8; ++blk) {
+      // draws 0..11 dof offset, 12..23 dof vel, 24..25 xy, 26..28 commands; four at a time
+      auto draw4 = [&](int blk, float (&u)[4]) {
+        if (a.r.u_dof_offset) {
+          if (blk < 3) {
+            const float4 v = *reinterpret_cast<const float4*>(a.r.u_dof_offset + k * AD + 4 * blk);
+            u[0] = v.x; u[1] = v.y; u[2] = v.z; u[3] = v.w;
+          } else if (blk < 6) {
+            const float4 v = *reinterpret_cast<const float4*>(a.r.u_dof_vel + k * AD + 4 * (blk - 3));
+            u[0] = v.x; u[1] = v.y; u[2] = v.z; u[3] = v.w;
+          } else if (blk == 6) {
+            u[0] = a.r.u_xy[k * 2]; u[1] = a.r.u_xy[k * 2 + 1]; u[2] = a.r.u_cmd[k * 3]; u[3] = a.r.u_cmd[k * 3 + 1];
+          } else {
+            u[0] = a.r.u_cmd[k * 3 + 2]; u[1] = u[2] = u[3] = 0.f;
+          }
+        } else {
           const u4 c{(uint32_t)env, (uint32_t)blk | (1u << 16), (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
           const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
-          const uint32_t w[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-          for (int qd = 0; qd < 4; ++qd)
-            if (4 * blk + qd < 29) u[4 * blk + qd] = u01(w[qd]);
+          u[0] = u01(x.x); u[1] = u01(x.y); u[2] = u01(x.z); u[3] = u01(x.w);
         }
-      }
+      };
+      float4* dpo = reinterpret_cast<float4*>(a.r.dof_pos_out + k * AD);
+      float4* dvo = reinterpret_cast<float4*>(a.r.dof_vel_out + k * AD);
 #pragma unroll
-      for (int j = 0; j < AD; ++j) {
-        dp[j] = p.default_dof_pos[j] * (1.0f * u[j] + 0.5f);  // :321,:324  U(0.5,1.5)
-        dv[j] = 0.2f * u[AD + j] + (-0.1f);                    // :322,:325  U(-0.1,0.1)
+      for (int c = 0; c < 3; ++c) {
+        float u[4], w[4];
+        draw4(c, u);
+        draw4(3 + c, w);
+        float4 dp, dv;
+        dp.x = p.default_dof_pos[4 * c + 0] * (1.0f * u[0] + 0.5f);  // :321,:324  U(0.5,1.5)
+        dp.y = p.default_dof_pos[4 * c + 1] * (1.0f * u[1] + 0.5f);
+        dp.z = p.default_dof_pos[4 * c + 2] * (1.0f * u[2] + 0.5f);
+        dp.w = p.default_dof_pos[4 * c + 3] * (1.0f * u[3] + 0.5f);
+        dv.x = 0.2f * w[0] + (-0.1f);  // :322,:325  U(-0.1,0.1)
+        dv.y = 0.2f * w[1] + (-0.1f);
+        dv.z = 0.2f * w[2] + (-0.1f);
+        dv.w = 0.2f * w[3] + (-0.1f);
+        dpo[c] = dp;
+        dvo[c] = dv;
+        *reinterpret_cast<float4*>(row + L_DPOS + 4 * c) = dp;  // the observation sees the reset DOF state
+        *reinterpret_cast<float4*>(row + L_DVEL + 4 * c) = dv;
       }
+      float u6[4], u7[4];
+      draw4(6, u6);
+      draw4(7, u7);
       const int64_t type = a.b.terrain_types[env];
       f3 origin{a.b.env_origins[env * 3], a.b.env_origins[env * 3 + 1], a.b.env_origins[env * 3 + 2]};
       if (p.init_done && p.curriculum) {  // update_terrain_level :369-380
@@ -319,24 +374,17 @@ __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __r
         a.b.terrain_levels[env] = level;
         a.b.env_origins[env * 3] = origin.x; a.b.env_origins[env * 3 + 1] = origin.y; a.b.env_origins[env * 3 + 2] = origin.z;
       }
-      hpos = f3{(p.base_init_state[0] + origin.x) + (1.0f * u[24] + (-0.5f)),
-                (p.base_init_state[1] + origin.y) + (1.0f * u[25] + (-0.5f)), p.base_init_state[2] + origin.z};  // :328-330
+      hpos = f3{(p.base_init_state[0] + origin.x) + (1.0f * u6[0] + (-0.5f)),
+                (p.base_init_state[1] + origin.y) + (1.0f * u6[1] + (-0.5f)), p.base_init_state[2] + origin.z};  // :328-330
       hq = q4{p.base_init_state[3], p.base_init_state[4], p.base_init_state[5], p.base_init_state[6]};           // :331
       a.r.base_pos_out[k * 3] = hpos.x; a.r.base_pos_out[k * 3 + 1] = hpos.y; a.r.base_pos_out[k * 3 + 2] = hpos.z;
       *reinterpret_cast<float4*>(a.r.base_quat_out + k * 4) = make_float4(hq.w, hq.x, hq.y, hq.z);
 #pragma unroll
       for (int c = 0; c < 6; ++c) a.r.base_vel_out[k * 6 + c] = p.base_init_state[7 + c];  // :332
-      float4* dpo = reinterpret_cast<float4*>(a.r.dof_pos_out + k * AD);
-      float4* dvo = reinterpret_cast<float4*>(a.r.dof_vel_out + k * AD);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        dpo[c] = make_float4(dp[4 * c], dp[4 * c + 1], dp[4 * c + 2], dp[4 * c + 3]);
-        dvo[c] = make_float4(dv[4 * c], dv[4 * c + 1], dv[4 * c + 2], dv[4 * c + 3]);
-      }
       // commands (:341-352)
-      cmd[0] = p.cmd_span[0] * u[26] + p.cmd_lo[0];
-      cmd[1] = p.cmd_span[1] * u[27] + p.cmd_lo[1];
-      cmd[3] = p.cmd_span[2] * u[28] + p.cmd_lo[2];
+      cmd[0] = p.cmd_span[0] * u6[2] + p.cmd_lo[0];
+      cmd[1] = p.cmd_span[1] * u6[3] + p.cmd_lo[1];
+      cmd[3] = p.cmd_span[2] * u7[0] + p.cmd_lo[2];
       const float keep = norm3(f3{cmd[0], cmd[1], 0.0f}) > 0.25f ? 1.0f : 0.0f;
 #pragma unroll
       for (int c = 0; c < 4; ++c) cmd[c] *= keep;
@@ -366,107 +414,236 @@ __device__ __forceinline__ void anymal_post_tile(const AnymalPost& a, float* __r
       if (step || reset) {  // standalone reset_idx: last_actions = last_dof_vel = 0 for env_ids (:354-355)
         float4* lao = reinterpret_cast<float4*>(a.b.last_actions + env * AD);
         float4* ldo = reinterpret_cast<float4*>(a.b.last_dof_vel + env * AD);
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          lao[c] = step ? make_float4(act[4 * c], act[4 * c + 1], act[4 * c + 2], act[4 * c + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-          ldo[c] = step ? make_float4(dv[4 * c], dv[4 * c + 1], dv[4 * c + 2], dv[4 * c + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          lao[c] = step ? lds4(row + L_ACT + 4 * c) : z4;
+          ldo[c] = step ? lds4(row + L_DVEL + 4 * c) : z4;
         }
       }
     }
-    // observation head (:540-550)
-    row[0] = lin.x * p.lin_vel_scale; row[1] = lin.y * p.lin_vel_scale; row[2] = lin.z * p.lin_vel_scale;
-    row[3] = ang.x * p.ang_vel_scale; row[4] = ang.y * p.ang_vel_scale; row[5] = ang.z * p.ang_vel_scale;
-    row[6] = grav.x; row[7] = grav.y; row[8] = grav.z;
-    row[9] = cmd[0] * p.lin_vel_scale; row[10] = cmd[1] * p.lin_vel_scale; row[11] = cmd[2] * p.ang_vel_scale;
+    if (step) {
+      // observation head (:540-550), in place over the row's first 36 columns
+      *reinterpret_cast<float4*>(row + 0) = make_float4(lin.x * p.lin_vel_scale, lin.y * p.lin_vel_scale, lin.z * p.lin_vel_scale,
+                                                        ang.x * p.ang_vel_scale);
+      *reinterpret_cast<float4*>(row + 4) = make_float4(ang.y * p.ang_vel_scale, ang.z * p.ang_vel_scale, grav.x, grav.y);
+      *reinterpret_cast<float4*>(row + 8) = make_float4(grav.z, cmd[0] * p.lin_vel_scale, cmd[1] * p.lin_vel_scale,
+                                                        cmd[2] * p.ang_vel_scale);
 #pragma unroll
-    for (int j = 0; j < AD; ++j) {
-      row[C_DPOS + j] = dp[j] * p.dof_pos_scale;
-      row[C_DVEL + j] = dv[j] * p.dof_vel_scale;
+      for (int c = 0; c < 3; ++c) {
+        const float4 dp = lds4(row + L_DPOS + 4 * c), dv = lds4(row + L_DVEL + 4 * c);
+        *reinterpret_cast<float4*>(row + L_DPOS + 4 * c) =
+            make_float4(dp.x * p.dof_pos_scale, dp.y * p.dof_pos_scale, dp.z * p.dof_pos_scale, dp.w * p.dof_pos_scale);
+        *reinterpret_cast<float4*>(row + L_DVEL + 4 * c) =
+            make_float4(dv.x * p.dof_vel_scale, dv.y * p.dof_vel_scale, dv.z * p.dof_vel_scale, dv.w * p.dof_vel_scale);
+      }
+      // yaw-only quaternion (:609-611): zero x,y then normalize (4-wide row: unfused sum)
+      const float yn = norm4(q4{hq.w, 0.0f, 0.0f, hq.z});
+      const float yd = yn < 1e-9f ? 1e-9f : yn;
+      // the pose the scan kernel works from; (:538) base z - 0.5 is the same subtraction for each of the env's 140 points
+      if (live) {
+        *reinterpret_cast<float4*>(pose_out + tid * APOSE) = make_float4(hq.w / yd, hq.z / yd, hpos.x, hpos.y);
+        *reinterpret_cast<float4*>(pose_out + tid * APOSE + 4) = make_float4(hpos.z - 0.5f, 0.f, 0.f, 0.f);
+      }
     }
-    // yaw-only quaternion (:609-611): zero x,y then normalize (4-wide row: unfused sum)
-    const float yn = norm4(q4{hq.w, 0.0f, 0.0f, hq.z});
-    const float yd = yn < 1e-9f ? 1e-9f : yn;
-    *reinterpret_cast<float4*>(s_pose + tid * 4) = make_float4(hq.w / yd, hq.z / yd, hpos.x, hpos.y);
-    s_pz[tid] = hpos.z - 0.5f;  // (:538) base z - 0.5, the same subtraction for each of the env's 140 points
   }
   if (!step) return;  // uniform across the workgroup
   __syncthreads();
 
-  // ---- height scan (:582-604, :537-539): 64 x 140 points over 256 threads
-#ifndef OIGE_EXP_NO_SCAN
-  // quat_apply(q_yaw, (hx, hy, 0)) with q_yaw = (w, 0, 0, z) (:608-612), written out with the terms that are exactly
-  // zero removed (the surviving products, sums and their order are oige_math.hpp's quat_apply: t = 2 (qv x v);
-  // v + w t + qv x t), so every finite result is bit-identical:
-  //   t = (-(2 z hy), 2 z hx, 0)      qv x t = (-(z t.y), z t.x, 0)
-  const int hs_cols = p.hs_cols, max_r = p.hs_rows - 2, max_c = p.hs_cols - 2;
-#pragma unroll 2
-  for (int pidx = tid; pidx < TILE * AP; pidx += ANT) {
-    const int e = pidx / AP, k = pidx - e * AP;
-    const float hx = s_hx[k], hy = s_hy[k];
-    const float4 ps = *reinterpret_cast<const float4*>(s_pose + e * 4);  // w, z, px, py
-    const float tx = -((ps.y * hy) * 2.0f), ty = (ps.y * hx) * 2.0f;
-    const float rx = (hx + ps.x * tx) + (-(ps.y * ty));
-    const float ry = (hy + ps.x * ty) + (ps.y * tx);
-    const float wx = ((rx + ps.z) + p.border_size) / p.horizontal_scale;  // :586-593
-    const float wy = ((ry + ps.w) + p.border_size) / p.horizontal_scale;
-    // .long() truncates toward zero; v_cvt_i32_f32 does too and saturates, and the clip that follows (:596-597) maps
-    // every saturated value where int64 truncation + clip would (out-of-range low -> 0, high -> rows - 2)
-    int px = (int)wx, py = (int)wy;
-    px = px < 0 ? 0 : (px > max_r ? max_r : px);
-    py = py < 0 ? 0 : (py > max_c ? max_c : py);
-    const int idx = px * hs_cols + py;
-    const int16_t h1 = a.s.height_samples[idx];
-    const int16_t h2 = a.s.height_samples[idx + hs_cols + 1];
-    const float mh = (float)(h1 < h2 ? h1 : h2) * p.vertical_scale;
-    float hv = s_pz[e] - mh;
-    hv = (hv != hv) ? hv : (hv < -1.0f ? -1.0f : (hv > 1.0f ? 1.0f : hv));
-    obs_t[e * AO + 36 + k] = hv * p.height_meas_scale;
-  }
-#endif
-  __syncthreads();
-
-  // ---- D: obs tile -> HBM with the uniform noise (:438-439)
-  constexpr int NF4 = TILE * AO / 4;
+  // ---- D1: head (cols 0:36) and actions (cols 176:188) of every row -> obs_buf with their noise
+  {
+    constexpr int HF4 = TILE * 12;  // 9 + 3 float4 per env
 #pragma unroll
-  for (int it = 0; it < (NF4 + ANT - 1) / ANT; ++it) {
-    const int f = it * ANT + tid;
-    if (f >= NF4) continue;
-    const int e = 4 * f;
-    if (!FULLTILE && e >= nv * AO) continue;  // AO % 4 == 0: a float4 is wholly valid or wholly not
-    float4 v = *reinterpret_cast<const float4*>(obs_t + e);
+    for (int it = 0; it < HF4 / WAVE; ++it) {
+      const int f = it * WAVE + tid;
+      const int e = f / 12, j = f - 12 * e;
+      if (!FULLTILE && e >= nv) continue;
+      const int lcol = 4 * j;                            // LDS column: head 0:36, actions 36:48
+      const int ocol = j < 9 ? lcol : 176 + (lcol - 36);  // observation column
+      float4 v = lds4(rows + e * ARW + lcol);
+      const int64_t off = (env0 + e) * AO + ocol;
 #ifndef OIGE_EXP_NO_NOISE
-    if (p.add_noise) {
-      const int c = e % AO;  // 4 consecutive columns of one row; region boundaries are multiples of 4 except 3/6/9
-      float uu[4];
-      const int64_t gf = (env0 * AO + e) / 4;
-      if (a.r.noise_u) {
-        const float4 t4 = *reinterpret_cast<const float4*>(a.r.noise_u + env0 * AO + e);
-        uu[0] = t4.x; uu[1] = t4.y; uu[2] = t4.z; uu[3] = t4.w;
-      } else {
-        const u4 cc{(uint32_t)gf, (uint32_t)(gf >> 32) | (3u << 16), (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
-        const u4 x = philox4x32_10(cc, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
-        uu[0] = u01(x.x); uu[1] = u01(x.y); uu[2] = u01(x.z); uu[3] = u01(x.w);
+      if (p.add_noise) {
+        float uu[4];
+        anymal_noise4(a.r, off, uu);
+        const float4 sc = lds4(s_ns + lcol);
+        v.x = v.x + (2.0f * uu[0] - 1.0f) * sc.x;
+        v.y = v.y + (2.0f * uu[1] - 1.0f) * sc.y;
+        v.z = v.z + (2.0f * uu[2] - 1.0f) * sc.z;
+        v.w = v.w + (2.0f * uu[3] - 1.0f) * sc.w;
       }
-      const float4 sc = *reinterpret_cast<const float4*>(s_ns + c);
-      float vv[4] = {v.x, v.y, v.z, v.w};
-      const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) vv[k] = vv[k] + (2.0f * uu[k] - 1.0f) * scv[k];
-      v = make_float4(vv[0], vv[1], vv[2], vv[3]);
-    }
 #endif
-    *reinterpret_cast<float4*>(a.b.obs_buf + env0 * AO + e) = v;
+      *reinterpret_cast<float4*>(a.b.obs_buf + off) = v;
+    }
   }
 }
 
-__global__ __launch_bounds__(ANT) void anymal_post_kernel(const AnymalPost a) {
-  extern __shared__ __align__(16) float lds[];
+__global__ __launch_bounds__(WAVE) void anymal_head_kernel(const AnymalPost a) {
+  __shared__ __align__(16) float lds[TILE * ARW + 48];
   const int64_t t = blockIdx.x;
   const int64_t left = a.n - t * TILE;
   if (left >= TILE)
-    anymal_post_tile<true>(a, lds, t, TILE);
+    anymal_head_tile<true>(a, lds, t, TILE);
   else
-    anymal_post_tile<false>(a, lds, t, (int)left);
+    anymal_head_tile<false>(a, lds, t, (int)left);
+}
+
+// ------------------------------------------------------------------ height scan (:582-604, :537-539)
+// One 256-thread workgroup per tile, from the pose records the head kernel left.  Each wave takes chunks of 256
+// consecutive points (64 float4 of scan columns): NG passes with ONE POINT PER LANE (64 neighbouring points of one env
+// per gather instruction, all gathers of a chunk issued before the first is consumed) into a per-wave LDS strip; then
+// one float4 per lane out of the strip, plus its noise, straight to obs_buf.  Light on registers and LDS on purpose:
+// the gathers are L2 / Infinity-Cache latency, hidden by resident waves.
+// The scan is VALU-issue bound (not gather bound: dropping both gathers saves 20 %), so the loop is kept lean:
+//  * quat_apply(q_yaw, (hx, hy, 0)) with q_yaw = (w, 0, 0, z) (:608-612), with the terms that are exactly zero removed
+//    (the surviving products, sums and their order are oige_math.hpp's quat_apply: t = 2 (qv x v); v + w t + qv x t, so
+//    every finite result is bit-identical):  t = (tx, ty, 0) = (-(2 z hy), 2 z hx, 0),
+//    rx = (hx + w tx) + (-(z ty)),  ry = (hy + w ty) + (z tx).  tx depends on the grid column only and ty on the grid
+//    row only: their four products are tabulated once per env (24 entries instead of 140 x 6 multiplies);
+//  * (env, point) cursors advance incrementally, no integer division in the loop;
+//  * x / horizontal_scale through div_by_const.
+constexpr int ANG = 4;
+// per-env scan table (floats): AB[iy] = (w tx, z tx) for the 10 grid columns, CD[ix] = (z ty, w ty) for the 14 grid
+// rows, then (base x, base y, base z - 0.5, -).  13 float4 per env (odd): conflict-free 16-byte rows.
+constexpr int AER = 52, AE_CD = 20, AE_POS = 48;
+
+__device__ __forceinline__ void cursor_advance(int& e, int& k, int de, int dk, int period) {
+  e += de;
+  k += dk;
+  if (k >= period) { k -= period; e += 1; }
+}
+
+template <bool FULLTILE>
+__device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __restrict__ s_env, float* __restrict__ s_k,
+                                                 float* __restrict__ s_strip, int64_t t, int nv) {
+  const oige_anymal_params& p = a.p;
+  const int tid = threadIdx.x;
+  const int64_t env0 = t * TILE;
+  const float* pose_in = a.b.reduce_workspace + pose_offset(num_tiles(a.n)) + env0 * APOSE;
+  if (tid < AP) {  // meshgrid(x, y, indexing='ij') flattened: k = ix * 10 + iy
+    const int ix = tid / 10, iy = tid % 10;
+    const float hx = 0.1f * (float)(ix < 7 ? ix - 8 : ix - 5);  // :178-180
+    const float hy = 0.1f * (float)(iy < 5 ? iy - 5 : iy - 4);  // :175-177
+    *reinterpret_cast<float4*>(s_k + 4 * tid) = make_float4(hx, hy, __int_as_float(8 * iy), __int_as_float(4 * AE_CD + 8 * ix));
+  }
+  {
+    constexpr int ENTRIES = TILE * 25;  // 24 table entries + the position record per env
+#pragma unroll
+    for (int it = 0; it < (ENTRIES + ANT - 1) / ANT; ++it) {
+      const int i = it * ANT + tid;
+      if (i >= ENTRIES) continue;
+      const int e = i / 25, j = i - 25 * e;
+      if (!FULLTILE && e >= nv) continue;
+      const float4 q = *reinterpret_cast<const float4*>(pose_in + e * APOSE);  // w, z, x, y (L2-hot: just written)
+      if (j < 10) {
+        const float hy = 0.1f * (float)(j < 5 ? j - 5 : j - 4);
+        const float tx = -((q.y * hy) * 2.0f);
+        *reinterpret_cast<float2*>(s_env + e * AER + 2 * j) = make_float2(q.x * tx, q.y * tx);
+      } else if (j < 24) {
+        const int ix = j - 10;
+        const float hx = 0.1f * (float)(ix < 7 ? ix - 8 : ix - 5);
+        const float ty = (q.y * hx) * 2.0f;
+        *reinterpret_cast<float2*>(s_env + e * AER + 2 * j) = make_float2(q.y * ty, q.x * ty);
+      } else {
+        *reinterpret_cast<float4*>(s_env + e * AER + AE_POS) = make_float4(q.z, q.w, pose_in[e * APOSE + 4], 0.f);
+      }
+    }
+  }
+  __syncthreads();
+#ifndef OIGE_EXP_NO_SCAN
+  const int hs_cols = p.hs_cols, max_r = p.hs_rows - 2, max_c = p.hs_cols - 2;
+  const float hscale = p.horizontal_scale, hinv = 1.0f / p.horizontal_scale;
+  const float nscale = p.noise_scales[5];
+  const int wave = tid >> 6, lane = tid & (WAVE - 1);
+  constexpr int NW = ANT / WAVE;
+  float* strip = s_strip + wave * 256;
+  constexpr int CHUNKS = TILE * AP / 256;  // 35
+  static_assert(TILE * AP % 256 == 0, "whole chunks");
+  // point cursor (env, k) of pass 0 of chunk `wave`; float4 cursor (env, k4) of its output
+  int pe = (wave * 256 + lane) / AP, pk = (wave * 256 + lane) - pe * AP;
+  int fe = (wave * WAVE + lane) / AP4, fk = (wave * WAVE + lane) - fe * AP4;
+#pragma unroll 1
+  for (int c = wave; c < CHUNKS; c += NW) {
+    int idx[ANG];
+    float pz[ANG];
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) {
+      const float4 kk = lds4(s_k + 4 * pk);  // hx, hy, AB offset, CD offset
+      const char* eb = reinterpret_cast<const char*>(s_env + pe * AER);
+      const float2 ab = *reinterpret_cast<const float2*>(eb + __float_as_int(kk.z));
+      const float2 cd = *reinterpret_cast<const float2*>(eb + __float_as_int(kk.w));
+      const float4 pp = *reinterpret_cast<const float4*>(eb + 4 * AE_POS);  // base x, y, z - 0.5
+      const float rx = (kk.x + ab.x) + (-cd.x);
+      const float ry = (kk.y + cd.y) + ab.y;
+      const float wx = div_by_const((rx + pp.x) + p.border_size, hscale, hinv);  // :586-593
+      const float wy = div_by_const((ry + pp.y) + p.border_size, hscale, hinv);
+      // .long() truncates toward zero; v_cvt_i32_f32 does too and saturates, and the clip that follows (:596-597) maps
+      // every saturated value where int64 truncation + clip would (out-of-range low -> 0, high -> rows - 2)
+      int px = (int)wx, py = (int)wy;
+      px = max(min(px, max_r), 0);
+      py = max(min(py, max_c), 0);
+      idx[g] = px * hs_cols + py;
+      pz[g] = pp.z;
+      // next pass: +64 points; after the last pass, the first pass of the wave's next chunk: +4*256 - 192 = 5*140 + 132
+      if (g != ANG - 1) cursor_advance(pe, pk, 0, 64, AP);
+      else cursor_advance(pe, pk, 5, 132, AP);
+    }
+    int16_t h1[ANG], h2[ANG];
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) {
+#if defined(OIGE_EXP_SCAN_NOGATHER)
+      h1[g] = (int16_t)idx[g];
+      h2[g] = (int16_t)(idx[g] >> 3);
+#else
+      h1[g] = a.s.height_samples[idx[g]];
+      h2[g] = a.s.height_samples[idx[g] + hs_cols + 1];
+#endif
+    }
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) {
+      const float mh = (float)(h1[g] < h2[g] ? h1[g] : h2[g]) * p.vertical_scale;
+      const float hv = pz[g] - mh;
+      const float cl = __builtin_fminf(__builtin_fmaxf(hv, -1.0f), 1.0f);
+      strip[g * WAVE + lane] = ((hv != hv) ? hv : cl) * p.height_meas_scale;  // torch.clip keeps NaN
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      float4 v = lds4(strip + 4 * lane);
+      const int64_t off = (env0 + fe) * AO + 36 + 4 * fk;
+      if (FULLTILE || fe < nv) {
+#ifndef OIGE_EXP_NO_NOISE
+        if (p.add_noise) {
+          float uu[4];
+          anymal_noise4(a.r, off, uu);
+          v.x = v.x + (2.0f * uu[0] - 1.0f) * nscale;
+          v.y = v.y + (2.0f * uu[1] - 1.0f) * nscale;
+          v.z = v.z + (2.0f * uu[2] - 1.0f) * nscale;
+          v.w = v.w + (2.0f * uu[3] - 1.0f) * nscale;
+        }
+#endif
+        *reinterpret_cast<float4*>(a.b.obs_buf + off) = v;
+      }
+      cursor_advance(fe, fk, 7, 11, AP4);  // the wave's next chunk: +4 * 64 float4 = 7 * 35 + 11
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+#endif
+}
+
+__global__ __launch_bounds__(ANT) void anymal_scan_kernel(const AnymalPost a) {
+  __shared__ __align__(16) float s_env[TILE * AER];
+  __shared__ __align__(16) float s_k[AP * 4];
+  __shared__ __align__(16) float s_strip[(ANT / WAVE) * 256];
+  const int64_t t = blockIdx.x;
+  const int64_t left = a.n - t * TILE;
+  if (left >= TILE)
+    anymal_scan_tile<true>(a, s_env, s_k, s_strip, t, TILE);
+  else
+    anymal_scan_tile<false>(a, s_env, s_k, s_strip, t, (int)left);
 }
 
 // extras (:361-367): mean over the reset envs of each episode sum / max_episode_length_s, mean terrain level
@@ -550,7 +727,7 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
                    aligned16(b.obs_buf) && aligned16(b.commands) && aligned16(b.actions) && aligned16(b.last_actions) &&
                    aligned16(b.last_dof_vel) && aligned16(b.torques) && aligned16(b.feet_air_time) && aligned16(r.base_quat_out) &&
                    aligned16(r.dof_pos_out) && aligned16(r.dof_vel_out) && aligned16(b.reset_workspace) &&
-                   aligned16(r.noise_u) && (reinterpret_cast<uintptr_t>(s.base_velocities) & 7u) == 0,
+                   aligned16(r.noise_u) && aligned16(b.reduce_workspace) && (reinterpret_cast<uintptr_t>(s.base_velocities) & 7u) == 0,
                "anymal: row buffers must be 16-byte aligned (base_velocities 8)");
   OIGE_REQUIRE(params->hs_rows >= 2 && params->hs_cols >= 2 && params->env_rows >= 1 && params->env_cols >= 1,
                "anymal: bad terrain dimensions");
@@ -569,9 +746,12 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
   if (int rc = launch_scan_groups(num_envs, b.reset_workspace, st)) return rc;
   hipLaunchKernelGGL(anymal_command_norm_kernel, dim3(1), dim3(1024), 0, st, b.reduce_workspace, T);
   if (int rc = check_launch("anymal_command_norm_kernel")) return rc;
-  const size_t lds = sizeof(float) * (TILE * AO + TILE * 4 + TILE + 2 * AP + AO);
-  hipLaunchKernelGGL(anymal_post_kernel, dim3((unsigned)T), dim3(ANT), lds, st, a);
-  if (int rc = check_launch("anymal_post_kernel")) return rc;
+  hipLaunchKernelGGL(anymal_head_kernel, dim3((unsigned)T), dim3(WAVE), 0, st, a);
+  if (int rc = check_launch("anymal_head_kernel")) return rc;
+  if (mode == 0) {
+    hipLaunchKernelGGL(anymal_scan_kernel, dim3((unsigned)T), dim3(ANT), 0, st, a);
+    if (int rc = check_launch("anymal_scan_kernel")) return rc;
+  }
   hipLaunchKernelGGL(anymal_extras_kernel, dim3(1), dim3(1024), 0, st, a);
   return check_launch("anymal_extras_kernel");
 }

@@ -203,7 +203,7 @@ class AnymalTerrainTask(RLTask):
         self._reset_bool = torch.zeros(n, dtype=torch.bool, device=dev)
         self._reset_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
         self._reset_workspace = _lib.new_workspace(n, dev)
-        self._reduce_workspace = torch.zeros(16 * tiles + 4, **f)
+        self._reduce_workspace = torch.zeros((16 + 512) * tiles + 4, **f)  # partial sums + pose records (oige_hip.h)
         self._extras_dev = torch.zeros(len(EPISODE_KEYS) + 1, **f)
         i64 = dict(dtype=torch.int64, device=dev)
         self._reset_out = {
