@@ -3,6 +3,8 @@ omni.isaac.core.utils.torch, which is not in the reference tree): algebraic inva
 facts the reference's own call sites fix."""
 import math
 
+import pytest
+
 import torch
 
 from oracle import torch_utils as tu
@@ -64,3 +66,19 @@ def test_normalize_eps():
     assert torch.equal(tu.normalize(torch.zeros(2, 3)), torch.zeros(2, 3))  # x / max(|x|, 1e-9)
     v = torch.tensor([[3.0, 4.0, 0.0]])
     assert torch.allclose(tu.normalize(v), torch.tensor([[0.6, 0.8, 0.0]]))
+
+
+def test_fma_division_by_constant_equals_ieee_division(tmp_path):
+    """csrc/anymal_terrain.hip div_by_const: q0 = x * RN(1/h), two fma residual corrections == RN(x / h) bit for bit."""
+    import os
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "div_check.c")
+    exe = str(tmp_path / "div_check")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm"], check=True)
+    out = subprocess.run([exe, "2000000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "mismatches 0" in out.stdout
