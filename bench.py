@@ -194,7 +194,7 @@ class AnymalBench:
         t.decimation = 1  # one PD-torque sub-step per env-step (the other three belong to the delegated physics loop)
         self.actions = st["actions"]
         self.post_bytes = ANYMAL_POST_BYTES
-        self.kernel = "anymal_post_kernel"
+        self.kernel = "anymal_head_kernel + anymal_scan_kernel (+ flags / scan / norm / extras: the whole post_physics_step)"
         self.workload = (f"AnymalTerrain height-scan obs(188) + 11-term reward + in-step reset + obs noise, {n} envs per GPU, "
                          "synthetic state, 1200x2000 int16 heightfield")
         self.extra_cfg = {"scan_points": 140, "decimation_substeps_timed": 1}

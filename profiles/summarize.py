@@ -16,7 +16,8 @@ import sys
 from collections import defaultdict
 
 
-DEFAULT_ENVS = {"Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}  # bench.py defaults
+DEFAULT_ENVS = {"Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18, "Anymal": 1 << 20,
+                "AllegroHand": 1 << 20}  # bench.py defaults
 
 
 def short(name: str) -> str:
@@ -50,7 +51,9 @@ def main() -> None:
     dst_dir = os.path.join("gpurun_out", f"summary_{tag}")
     os.makedirs(dst_dir, exist_ok=True)
     pmc = {}
-    for task in ("Ant", "Humanoid", "ShadowHand", "AnymalTerrain"):
+    for task in DEFAULT_ENVS:
+        if not os.path.isdir(os.path.join(root, task)):
+            continue
         kernel_stats(os.path.join(root, task), os.path.join(dst_dir, f"{task}_kernel_stats.csv"))
         merged = defaultdict(dict)
         for kind in ("fetch", "write"):
@@ -65,15 +68,23 @@ def main() -> None:
                 open(os.path.join(dst_dir, f"{task}.{ext}"), "w").write(txt)
     json.dump(pmc, open(os.path.join(dst_dir, "pmc_counters.json"), "w"), indent=1)
     # HBM bytes per launch of the dominant kernel: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, KiB -> bytes
-    dominant = {"Ant": "locomotion_post_kernel", "Humanoid": "locomotion_post_kernel", "ShadowHand": "hand_post_kernel",
-                "AnymalTerrain": "anymal_post_kernel"}
+    # (AnymalTerrain's post_physics_step is several kernels: their bytes are summed, as bench.py times them together)
+    dominant = {"Ant": ["locomotion_post_kernel"], "Humanoid": ["locomotion_post_kernel"], "ShadowHand": ["hand_post_kernel"],
+                "AnymalTerrain": ["anymal_head_kernel", "anymal_scan_kernel", "anymal_flags_kernel", "anymal_extras_kernel",
+                                  "anymal_command_norm_kernel", "scan_groups_kernel"],
+                "Anymal": ["anymal_flat_post_kernel"], "AllegroHand": ["allegro_post_kernel"]}
     traffic = {}
     for task, ks in pmc.items():
+        fetch = write = 0.0
+        names = []
         for k, cs in ks.items():
-            if dominant[task] in k and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-                fetch, write = cs["FETCH_SIZE"]["mean"] * 1024.0, cs["WRITE_SIZE"]["mean"] * 1024.0
-                traffic[task] = {"kernel": k, "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
-                                 "hbm_bytes_per_launch": 2.0 * fetch + write, "envs": DEFAULT_ENVS[task]}
+            if any(d in k for d in dominant[task]) and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                fetch += cs["FETCH_SIZE"]["mean"] * 1024.0
+                write += cs["WRITE_SIZE"]["mean"] * 1024.0
+                names.append(k)
+        if names:
+            traffic[task] = {"kernel": " + ".join(names), "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
+                             "hbm_bytes_per_launch": 2.0 * fetch + write, "envs": DEFAULT_ENVS[task]}
     json.dump(traffic, open(os.path.join(dst_dir, "traffic.json"), "w"), indent=1)
 
 
