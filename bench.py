@@ -119,24 +119,42 @@ class HandBench:
             v.apply_resets = False
         self.actions = st["actions"]
         self._noisy = torch.empty_like(self.actions)
-        self.post_bytes = HAND_POST_BYTES
+        self._obs_clamped = torch.empty_like(t.obs_buf)
+        # OIGE_BENCH_SEPARATE_DR=1: the noise as two separate launches (what VecEnvRLGames does with fused_dr = False)
+        self.fused_dr = os.environ.get("OIGE_BENCH_SEPARATE_DR", "0") != "1"
+        # in-kernel DR: the post kernel also reads the correlated noise (168), updates the counter (8) and writes the
+        # clamped copy the policy receives (168) next to the noised obs_buf
+        self.post_bytes = HAND_POST_BYTES + (168 + 8 + 168 if self.fused_dr else 0)
         self.kernel = "hand_post_kernel"
         self.workload = (f"ShadowHand openai obs(42) + full_state states(187) + goal-rotation reward + reset_target_pose/reset_idx "
-                         f"+ obs/action DR noise, {n} envs per GPU, synthetic state")
-        self.extra_cfg = {"observationType": t.obs_type, "asymmetric_observations": True, "dr_noise": True}
+                         f"+ obs/action DR noise ({'applied inside the pre/post kernels' if self.fused_dr else 'separate launches'}), "
+                         f"{n} envs per GPU, synthetic state")
+        self.extra_cfg = {"observationType": t.obs_type, "asymmetric_observations": True, "dr_noise": True,
+                          "dr_in_kernel": self.fused_dr}
 
     def pre(self):
         t = self.task
-        self._noisy.copy_(self.actions)
-        a = t._dr_randomizer.apply_actions_randomization(actions=self._noisy, reset_buf=t.reset_buf)
-        t.pre_physics_step(a)
+        self._noisy.copy_(self.actions)  # the policy's fresh actions (the noise is applied in place)
+        if self.fused_dr:
+            t.clamp_actions_in_kernel = True
+            t.pre_physics_step(self._noisy, action_noise=t._dr_randomizer.fused_actions_args(self._noisy))
+        else:
+            a = t._dr_randomizer.apply_actions_randomization(actions=self._noisy, reset_buf=t.reset_buf)
+            t.pre_physics_step(a)
 
     def post(self):
-        self.task.post_physics_step()
+        t = self.task
+        if self.fused_dr:
+            t.post_physics_step(obs_noise=t._dr_randomizer.fused_observations_args(t.obs_buf, clamped_out=self._obs_clamped,
+                                                                                   clip=t.clip_obs))
+        else:
+            t.post_physics_step()
 
     def after_post(self):  # wrapper-side observation noise (vec_env_rlgames.py:94-97); outside the post-kernel event bracket
         t = self.task
-        t._dr_randomizer.apply_observations_randomization(observations=t.obs_buf, reset_buf=t.reset_buf)
+        if not self.fused_dr:
+            t._dr_randomizer.apply_observations_randomization(observations=t.obs_buf, reset_buf=t.reset_buf,
+                                                              clamped_out=self._obs_clamped, clip=t.clip_obs)
 
     def resets(self):
         return int(self.task._reset_out["count"].item())

@@ -543,6 +543,22 @@ int oige_dr_noise_count(const oige_noise_args* args, int64_t num_envs, oige_stre
  * and optionally the clamped copy.  One launch.                                                   */
 int oige_dr_noise_apply(const oige_noise_args* args, int64_t num_envs, oige_stream_t stream);
 
+/* The in-hand kernels can apply the noise themselves (the wrapper's DR passes folded into the task
+ * kernels), in-kernel Philox samples only, values bit-identical to the separate oige_dr_noise_apply launch:
+ *   _post_physics_dr: vec_env_rlgames.py:94-97 -- observation noise with the reset_buf this very step produced, while the
+ *     obs tile streams out; obs_noise->buffer must be buffers->obs_buf (left noised, unclamped, as the reference leaves
+ *     it), ->clamped_out receives what _process_data (:40) hands the policy.  ShadowHand only (AllegroHand.yaml has no DR).
+ *   _pre_physics_dr: vec_env_rlgames.py:72-77 -- action noise with the reset_buf as it stands on entry, while the actions
+ *     are read; action_noise->buffer must be actions_inout (left noised, unclamped); with OIGE_PRE_CLAMP_ACTIONS
+ *     actions_out is the clamped clone the task keeps.  ->clamped_out must be NULL.                                      */
+int oige_hand_post_physics_dr(const oige_hand_params* params, const oige_hand_state* state,
+                              const oige_hand_buffers* buffers, const oige_noise_args* obs_noise,
+                              int64_t num_envs, uint32_t stages, oige_stream_t stream);
+int oige_hand_pre_physics_dr(const oige_hand_params* params, float* actions_inout,
+                             const oige_hand_buffers* buffers, const oige_hand_reset_io* reset_io,
+                             const oige_noise_args* action_noise, float* actions_out, float* targets_out,
+                             int64_t num_envs, uint32_t flags, oige_stream_t stream);
+
 /* ------------------------------------------------------------------ Cartpole
  * tasks/cartpole.py:91-164.                                                                 */
 typedef struct oige_cartpole_params {

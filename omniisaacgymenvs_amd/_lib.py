@@ -222,6 +222,10 @@ SIGNATURES = {
                                          C.c_uint32, _P]),
     "oige_hand_pre_physics": (C.c_int, [C.POINTER(HandParams), _P, C.POINTER(HandBuffers), C.POINTER(HandResetIO), _P, _P,
                                         C.c_int64, C.c_uint32, _P]),
+    "oige_hand_post_physics_dr": (C.c_int, [C.POINTER(HandParams), C.POINTER(HandState), C.POINTER(HandBuffers),
+                                            C.POINTER(NoiseArgs), C.c_int64, C.c_uint32, _P]),
+    "oige_hand_pre_physics_dr": (C.c_int, [C.POINTER(HandParams), _P, C.POINTER(HandBuffers), C.POINTER(HandResetIO),
+                                           C.POINTER(NoiseArgs), _P, _P, C.c_int64, C.c_uint32, _P]),
     "oige_hand_reset_idx": (C.c_int, [C.POINTER(HandParams), C.POINTER(HandBuffers), C.POINTER(HandResetIO), C.c_int64,
                                       C.c_int64, _P]),
     "oige_hand_reset_target_pose": (C.c_int, [C.POINTER(HandParams), C.POINTER(HandBuffers), C.POINTER(HandResetIO),

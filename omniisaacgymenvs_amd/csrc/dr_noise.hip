@@ -17,27 +17,9 @@
 // Box-Muller for the gaussian (no host sync, distribution parity only).
 #include "oige_common.hpp"
 #include "oige_math.hpp"
+#include "oige_noise.hpp"
 
 namespace oige {
-
-struct NoiseDecision {
-  bool reset, interval;
-  int cnt;
-};
-
-// counter logic of :284-286 and :299-304 for one env
-__device__ __forceinline__ NoiseDecision noise_decide(const oige_noise_args& a, int64_t env, bool live) {
-  NoiseDecision d{false, false, 0};
-  if (!live) return d;
-  d.reset = a.reset_buf[env] != 0;
-  int cnt = a.counter[env];
-  if (d.reset) cnt = 0;
-  cnt += 1;
-  d.interval = a.on_interval.enabled && cnt >= a.on_interval.frequency_interval;
-  if (d.interval) cnt = 0;
-  d.cnt = cnt;
-  return d;
-}
 
 __global__ __launch_bounds__(GROUP) void dr_noise_count_kernel(const oige_noise_args a, int64_t n) {
   const int64_t env = (int64_t)blockIdx.x * GROUP + threadIdx.x;
@@ -47,29 +29,6 @@ __global__ __launch_bounds__(GROUP) void dr_noise_count_kernel(const oige_noise_
     const int64_t t = (int64_t)blockIdx.x * GROUP_TILES + (threadIdx.x >> 6);
     a.reset_workspace[t] = __popcll(mr);
     a.interval_workspace[t] = __popcll(mi);
-  }
-}
-
-// four samples of one distribution from one Philox block
-__device__ __forceinline__ void noise_samples(const oige_noise_term& t, const u4 x, float out[4]) {
-  const float u[4] = {u01(x.x), u01(x.y), u01(x.z), u01(x.w)};
-  if (t.distribution == OIGE_NOISE_GAUSSIAN) {  // Box-Muller, two pairs; 1 - u in (0, 1]
-    // Hardware transcendentals (v_log_f32 = log2, v_sin/v_cos_f32 take REVOLUTIONS, so the angle 2*pi*u needs no
-    // multiply or range reduction): the precise libm calls made this kernel VALU-bound at 1.6 TB/s.  These
-    // samples are distribution-parity only (torch's RNG cannot be replayed in-kernel); they agree with the numpy
-    // restatement (oracle/dr_noise_oracle.py) to ~1e-6 relative.
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const float r = __builtin_amdgcn_sqrtf((-2.0f * 0.69314718055994530942f) * __builtin_amdgcn_logf(1.0f - u[2 * h]));
-      out[2 * h] = (r * __builtin_amdgcn_cosf(u[2 * h + 1])) * t.p1 + t.p0;
-      out[2 * h + 1] = (r * __builtin_amdgcn_sinf(u[2 * h + 1])) * t.p1 + t.p0;
-    }
-  } else if (t.distribution == OIGE_NOISE_UNIFORM) {  // (hi - lo) * rand + lo  (:353-355)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = t.p1 * u[k] + t.p0;
-  } else {  // exp((log hi - log lo) * rand + log lo)  (:357-361)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) out[k] = __expf(t.p1 * u[k] + t.p0);
   }
 }
 

@@ -20,6 +20,7 @@
 // (count, sum) pair per tile from a fixed shuffle tree, then a single-workgroup pass in tile order.
 #include "oige_common.hpp"
 #include "oige_math.hpp"
+#include "oige_noise.hpp"
 #include "oige_tile.hpp"
 
 namespace oige {
@@ -38,6 +39,10 @@ struct HandPost {
   uint32_t stages;
   float max_len_minus_1;   // (float)((double)max_episode_length - 1.0)
   float half_fall_penalty; // (float)(0.5 * (double)fall_penalty)
+  // observation noise applied while the obs tile streams out (randomize.py:283-312 + the clamp of
+  // vec_env_rlgames.py:40), instead of a separate pass over obs_buf; dr == 0: none
+  oige_noise_args dn;
+  int dr;
 };
 
 struct HandRewardOut {
@@ -179,12 +184,13 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
                                                   HandTileAcc& acc, const int tid) {
   constexpr int OW = OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157;
   constexpr bool NEED_FULLCOLS = ASYM || OBS == OIGE_HAND_OBS_FULL;
-  // LDS carve: [obs tile | states tile | env_pos HPEx3 | lo 24 | hi 24]
+  // LDS carve: [obs tile | states tile | env_pos HPEx3 | lo 24 | hi 24 | noise decisions HPE]
   float* obs_t = lds;
   float* st_t = lds + HPE * OW;
   float* s_env = st_t + (ASYM ? HPE * HS : 0);
   float* s_lo = s_env + HPE * 3;
   float* s_hi = s_lo + HD;
+  int* s_dec = reinterpret_cast<int*>(s_hi + HD);  // HPE noise decisions (dr only)
 
   const oige_hand_params& p = a.p;
   const bool do_progress = a.stages & OIGE_STAGE_PROGRESS;
@@ -300,6 +306,11 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
         a.b.successes[env] = o.successes;
         if (a.b.randomization_buf) a.b.randomization_buf[env] += 1;  // :297
       }
+      if (a.dr && envlane) {  // the wrapper hands the noise the reset_buf this step just produced (vec_env_rlgames.py:94-97)
+        const NoiseDecision d = noise_decide_flag(a.dn, env, live, live && o.resets != 0);
+        if (live) a.dn.counter[env] = d.cnt;
+        s_dec[tid] = (d.reset ? 1 : 0) | (d.interval ? 2 : 0);
+      }
       const bool r1 = live && o.resets != 0, g1 = live && o.goal_resets != 0;
       const unsigned long long mr = __ballot(r1), mg = __ballot(g1);
       // Sum(resets) counts VALUES (a stale reset_buf could hold values other than 0/1)
@@ -315,7 +326,54 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
 
   // ---- D: tiles -> HBM
   if (a.stages & OIGE_STAGE_OBS) {
-    wg_store_tile<OW, HNT, FULL, HPE>(obs_t, a.b.obs_buf + env0 * OW, nv * OW, tid);
+    if (a.dr) {
+      // obs tile -> noise -> obs_buf (noised, as the reference leaves it) and the clamped copy the policy gets
+      constexpr int NF4 = (HPE * OW) / 4;
+      const int64_t base = env0 * OW;  // a multiple of 4: env0 is a multiple of HPE and HPE * OW % 4 == 0
+      const int total = nv * OW;
+      const bool has_reset = a.dn.on_reset.enabled != 0;
+#pragma unroll 1
+      for (int f = tid; f < NF4; f += HNT) {
+        const int e = 4 * f;
+        if (!FULL && e >= total) break;
+        const int nvalid = FULL ? 4 : (total - e < 4 ? total - e : 4);
+        const float4 t4 = *reinterpret_cast<const float4*>(obs_t + e);
+        float v[4] = {t4.x, t4.y, t4.z, t4.w}, c[4] = {0.f, 0.f, 0.f, 0.f};
+        float* cor = a.dn.correlated_noise + base + e;
+        if (has_reset) {
+          if (nvalid == 4) {
+            const float4 q = *reinterpret_cast<const float4*>(cor);
+            c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w;
+          } else {
+            for (int k = 0; k < nvalid; ++k) c[k] = cor[k];
+          }
+        }
+        int le = e / OW, col = e - le * OW, dec[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          dec[k] = s_dec[le < HPE ? le : HPE - 1];
+          if (++col == OW) { col = 0; ++le; }
+        }
+        const bool dirty = noise_apply4(a.dn, dec, nvalid, (base + e) >> 2, v, c);
+        float* ob = a.b.obs_buf + base + e;
+        float* cl = a.dn.clamped_out ? a.dn.clamped_out + base + e : nullptr;
+        if (nvalid == 4) {
+          *reinterpret_cast<float4*>(ob) = make_float4(v[0], v[1], v[2], v[3]);
+          if (dirty) *reinterpret_cast<float4*>(cor) = make_float4(c[0], c[1], c[2], c[3]);
+          if (cl)
+            *reinterpret_cast<float4*>(cl) = make_float4(clamp_sym(v[0], a.dn.clip), clamp_sym(v[1], a.dn.clip),
+                                                         clamp_sym(v[2], a.dn.clip), clamp_sym(v[3], a.dn.clip));
+        } else {
+          for (int k = 0; k < nvalid; ++k) {
+            ob[k] = v[k];
+            if (dirty) cor[k] = c[k];
+            if (cl) cl[k] = clamp_sym(v[k], a.dn.clip);
+          }
+        }
+      }
+    } else {
+      wg_store_tile<OW, HNT, FULL, HPE>(obs_t, a.b.obs_buf + env0 * OW, nv * OW, tid);
+    }
     if (ASYM) wg_store_tile<HS, HNT, FULL, HPE>(st_t, a.b.states_buf + env0 * HS, nv * HS, tid);
   }
 }
@@ -560,6 +618,10 @@ struct HandPre {
   float* targets_out;
   int64_t n;
   uint32_t flags;
+  // action noise applied while the actions are read (randomize.py:314-342), instead of a separate pass; dr == 0: none.
+  // dn.buffer == actions_in: the caller's tensor receives the noised (unclamped) values, as in the reference.
+  oige_noise_args dn;
+  int dr;
 };
 
 // U(-1,1) from Philox: torch_rand_float(-1, 1): (1 - (-1)) * u + (-1)
@@ -705,6 +767,7 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
   __shared__ int lds_a[GROUP_TILES], lds_b[GROUP_TILES];
   __shared__ int s_list_r[GROUP], s_list_g[GROUP], s_rank[GROUP];
   __shared__ int s_inv[D];
+  __shared__ int s_dec[GROUP];
   __shared__ __align__(16) float s_act[GROUP * A];
   const oige_hand_params& p = a.p;
   const int tid = threadIdx.x;
@@ -717,6 +780,11 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
   const bool f_env = live && a.b.reset_buf[env] != 0;
   const bool f_goal = live && a.b.reset_goal_buf[env] != 0;
   if (tid < D) s_inv[tid] = -1;
+  if (a.dr) {  // the wrapper hands the noise the reset_buf as it stands before this step's resets (vec_env_rlgames.py:72-75)
+    const NoiseDecision d = noise_decide_flag(a.dn, env, live, f_env);
+    if (live) a.dn.counter[env] = d.cnt;
+    s_dec[tid] = (d.reset ? 1 : 0) | (d.interval ? 2 : 0);
+  }
   const int64_t kg = group_rank(f_goal, off_g, g, lds_b);  // (barrier inside)
   const int64_t kr = group_rank(f_env, off_r, g, lds_a);
   const int32_t k0g = off_g[g], k0r = off_r[g];
@@ -736,6 +804,20 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
       const int f = it * GROUP + tid;
       if (f < nf4) {
         float4 v = *reinterpret_cast<const float4*>(a.actions_in + base + 4 * f);
+        if (a.dr) {  // A % 4 == 0: the four elements belong to one env
+          float vv[4] = {v.x, v.y, v.z, v.w}, c[4] = {0.f, 0.f, 0.f, 0.f};
+          float* cor = a.dn.correlated_noise + base + 4 * f;
+          if (a.dn.on_reset.enabled) {
+            const float4 q = *reinterpret_cast<const float4*>(cor);
+            c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w;
+          }
+          const int de = s_dec[(4 * f) / A];
+          const int dec[4] = {de, de, de, de};
+          const bool dirty = noise_apply4(a.dn, dec, 4, (base >> 2) + f, vv, c);
+          v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+          *reinterpret_cast<float4*>(a.dn.buffer + base + 4 * f) = v;
+          if (dirty) *reinterpret_cast<float4*>(cor) = make_float4(c[0], c[1], c[2], c[3]);
+        }
         if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
           v.x = clamp_sym(v.x, p.clip_actions); v.y = clamp_sym(v.y, p.clip_actions);
           v.z = clamp_sym(v.z, p.clip_actions); v.w = clamp_sym(v.w, p.clip_actions);
@@ -892,7 +974,7 @@ static int check_hand(const oige_hand_params* p, const oige_hand_buffers* b, int
 template <int OBS, bool ASYM>
 static int launch_hand_post(const HandPost& a, hipStream_t s) {
   constexpr int OW = OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157;
-  const size_t lds = sizeof(float) * (HPE * OW + (ASYM ? HPE * HS : 0) + HPE * 3 + 2 * HD);
+  const size_t lds = sizeof(float) * (HPE * OW + (ASYM ? HPE * HS : 0) + HPE * 3 + 2 * HD + HPE);
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hand_post_kernel<OBS, ASYM>),
@@ -918,8 +1000,8 @@ using namespace oige;
 
 extern "C" {
 
-int oige_hand_post_physics(const oige_hand_params* params, const oige_hand_state* state,
-                           const oige_hand_buffers* buffers, int64_t num_envs, uint32_t stages, oige_stream_t stream) {
+static int hand_post_physics(const oige_hand_params* params, const oige_hand_state* state, const oige_hand_buffers* buffers,
+                             const oige_noise_args* noise, int64_t num_envs, uint32_t stages, oige_stream_t stream) {
   if (int rc = check_hand(params, buffers, num_envs)) return rc;
   OIGE_REQUIRE((stages & ~OIGE_STAGE_ALL) == 0 && stages != 0, "hand_post_physics: bad stages mask 0x%x", stages);
   stages &= ~OIGE_STAGE_DONE;  // is_done is `pass` in the reference (:374-375)
@@ -944,6 +1026,16 @@ int oige_hand_post_physics(const oige_hand_params* params, const oige_hand_state
   a.stages = stages;
   a.max_len_minus_1 = (float)((double)params->max_episode_length - 1.0);
   a.half_fall_penalty = (float)(0.5 * (double)params->fall_penalty);
+  a.dr = 0;
+  if (noise) {
+    OIGE_REQUIRE(!is_allegro(params), "hand_post_physics_dr: the AllegroHand task configures no observation noise (AllegroHand.yaml)");
+    OIGE_REQUIRE((stages & (OIGE_STAGE_OBS | OIGE_STAGE_METRICS)) == (OIGE_STAGE_OBS | OIGE_STAGE_METRICS),
+                 "hand_post_physics_dr: the noise needs this step's observations and reset flags (stages OBS | METRICS)");
+    if (int rc = noise_validate_fused(noise, b.obs_buf, params->obs_type == OIGE_HAND_OBS_OPENAI ? 42 : 157, "hand_post_physics_dr"))
+      return rc;
+    a.dn = *noise;
+    a.dr = 1;
+  }
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (is_allegro(params)) {
@@ -1001,15 +1093,16 @@ static int fill_pre(HandPre& a, const oige_hand_params* params, const oige_hand_
   a.r = *r;
   a.n = n;
   a.flags = 0;
+  a.dr = 0;
   a.actions_in = nullptr;
   a.actions_out = nullptr;
   a.targets_out = nullptr;
   return OIGE_OK;
 }
 
-int oige_hand_pre_physics(const oige_hand_params* params, const float* actions_in, const oige_hand_buffers* buffers,
-                          const oige_hand_reset_io* reset_io, float* actions_out, float* targets_out, int64_t num_envs,
-                          uint32_t flags, oige_stream_t stream) {
+static int hand_pre_physics(const oige_hand_params* params, const float* actions_in, const oige_hand_buffers* buffers,
+                            const oige_hand_reset_io* reset_io, const oige_noise_args* noise, float* actions_out,
+                            float* targets_out, int64_t num_envs, uint32_t flags, oige_stream_t stream) {
   HandPre a;
   if (int rc = fill_pre(a, params, buffers, reset_io, num_envs)) return rc;
   const oige_hand_reset_io& r = *reset_io;
@@ -1032,6 +1125,14 @@ int oige_hand_pre_physics(const oige_hand_params* params, const float* actions_i
   a.actions_out = actions_out;
   a.targets_out = targets_out;
   a.flags = flags;
+  if (noise) {
+    if (int rc = noise_validate_fused(noise, actions_in, is_allegro(params) ? OIGE_ALLEGRO_DOFS : OIGE_HAND_ACTIONS,
+                                      "hand_pre_physics_dr"))
+      return rc;
+    OIGE_REQUIRE(!noise->clamped_out, "hand_pre_physics_dr: the clamped actions are actions_out (OIGE_PRE_CLAMP_ACTIONS)");
+    a.dn = *noise;
+    a.dr = 1;
+  }
   const int64_t G = num_groups(num_envs);
   if (G == 0) return OIGE_OK;
   hipStream_t s = (hipStream_t)stream;
@@ -1046,6 +1147,32 @@ int oige_hand_pre_physics(const oige_hand_params* params, const float* actions_i
   else
     hipLaunchKernelGGL((hand_pre_kernel<OIGE_HAND_DOFS, OIGE_HAND_ACTIONS>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
   return check_launch("hand_pre_kernel");
+}
+
+int oige_hand_post_physics(const oige_hand_params* params, const oige_hand_state* state,
+                           const oige_hand_buffers* buffers, int64_t num_envs, uint32_t stages, oige_stream_t stream) {
+  return hand_post_physics(params, state, buffers, nullptr, num_envs, stages, stream);
+}
+
+int oige_hand_post_physics_dr(const oige_hand_params* params, const oige_hand_state* state,
+                              const oige_hand_buffers* buffers, const oige_noise_args* obs_noise, int64_t num_envs,
+                              uint32_t stages, oige_stream_t stream) {
+  OIGE_REQUIRE(obs_noise, "hand_post_physics_dr: null noise args");
+  return hand_post_physics(params, state, buffers, obs_noise, num_envs, stages, stream);
+}
+
+int oige_hand_pre_physics(const oige_hand_params* params, const float* actions_in, const oige_hand_buffers* buffers,
+                          const oige_hand_reset_io* reset_io, float* actions_out, float* targets_out, int64_t num_envs,
+                          uint32_t flags, oige_stream_t stream) {
+  return hand_pre_physics(params, actions_in, buffers, reset_io, nullptr, actions_out, targets_out, num_envs, flags, stream);
+}
+
+int oige_hand_pre_physics_dr(const oige_hand_params* params, float* actions_inout, const oige_hand_buffers* buffers,
+                             const oige_hand_reset_io* reset_io, const oige_noise_args* action_noise, float* actions_out,
+                             float* targets_out, int64_t num_envs, uint32_t flags, oige_stream_t stream) {
+  OIGE_REQUIRE(action_noise, "hand_pre_physics_dr: null noise args");
+  return hand_pre_physics(params, actions_inout, buffers, reset_io, action_noise, actions_out, targets_out, num_envs, flags,
+                          stream);
 }
 
 int oige_hand_reset_idx(const oige_hand_params* params, const oige_hand_buffers* buffers,

@@ -9,7 +9,10 @@ zero actions.  The recording branch (:55-70) needs a renderer and is reduced to 
 ``fused_io`` (default True) removes the wrapper's extra full passes over actions / obs / states without
 changing a value the policy sees:
   * ``torch.clamp(actions)`` (:77) is folded into the task's pre_physics kernel where it supports that;
-  * with DR, the noise kernel writes the clamped copy in the same launch (:94-97 + :40 in one pass);
+  * with DR, the noise kernel writes the clamped copy in the same launch (:94-97 + :40 in one pass); and where the
+    task supports it (``fused_dr``, the in-hand family) there is no noise launch at all: the pre_physics kernel noises
+    the actions as it reads them, the post_physics kernel noises and clamps the observations as it writes them
+    (same Philox samples, bit-identical values);
   * ``torch.clamp(x, -inf, inf)`` (clip key absent: Ant, Humanoid, AnymalTerrain's states) is skipped: the task's
     buffer itself is returned instead of a fresh copy of it.  A caller that keeps ``obs`` across ``step`` calls
     without copying it (rl_games copies it into its experience buffer first) should set ``fused_io = False``,
@@ -27,6 +30,7 @@ from .vec_env_base import VecEnvBase
 
 class VecEnvRLGames(VecEnvBase):
     fused_io = True
+    fused_dr = True  # with fused_io: tasks that can (the in-hand family) apply the DR noise inside their own kernels
     _obs_is_clamped = False
 
     def _clamp_obs(self, x):
@@ -77,7 +81,13 @@ class VecEnvRLGames(VecEnvBase):
         fused = self.fused_io and actions.device == torch.device(t.device) and actions.dtype == torch.float32
         finite_act_clip = not math.isinf(t.clip_actions)
         t.clamp_actions_in_kernel = False
-        if t.randomize_actions and fused and finite_act_clip and actions.is_contiguous():
+        in_kernel_dr = (fused and self.fused_dr and getattr(t, "supports_fused_dr", False) and t._dr_randomizer.sync_free
+                        and actions.is_contiguous() and self._world.is_playing())
+        action_noise = None
+        if t.randomize_actions and in_kernel_dr and t.supports_action_clamp:
+            action_noise = t._dr_randomizer.fused_actions_args(actions)
+            t.clamp_actions_in_kernel = finite_act_clip
+        elif t.randomize_actions and fused and finite_act_clip and actions.is_contiguous():
             clamped = self._persistent("_act_clamped", actions)  # noise + clamp in one launch
             t._dr_randomizer.apply_actions_randomization(actions=actions, reset_buf=t.reset_buf, clamped_out=clamped,
                                                          clip=t.clip_actions)
@@ -91,12 +101,24 @@ class VecEnvRLGames(VecEnvBase):
             else:
                 actions = torch.clamp(actions, -t.clip_actions, t.clip_actions).to(t.device)
 
-        t.pre_physics_step(actions)
+        if action_noise is not None:
+            t.pre_physics_step(actions, action_noise=action_noise)
+        else:
+            t.pre_physics_step(actions)
         t.clamp_actions_in_kernel = False
         self._advance_world(to_render)
-        self._obs, self._rew, self._resets, self._extras = t.post_physics_step()
 
         self._obs_is_clamped = False
+        if t.randomize_observations and in_kernel_dr and not math.isinf(t.clip_obs) and t.rl_device == t.device:
+            clamped = self._persistent("_obs_clamped", t.obs_buf)
+            noise = t._dr_randomizer.fused_observations_args(t.obs_buf, clamped_out=clamped, clip=t.clip_obs)
+            self._obs, self._rew, self._resets, self._extras = t.post_physics_step(obs_noise=noise)
+            self._obs, self._obs_is_clamped = clamped, True
+            self._states = t.get_states()
+            self._process_data()
+            return {"obs": self._obs, "states": self._states}, self._rew, self._resets, self._extras
+        self._obs, self._rew, self._resets, self._extras = t.post_physics_step()
+
         if t.randomize_observations:
             obs = self._obs.to(device=t.rl_device)
             if self.fused_io and not math.isinf(t.clip_obs) and obs.is_contiguous():

@@ -232,11 +232,16 @@ class InHandManipulationTask(RLTask):
         self._live_state = keep
         return s
 
-    def _post(self, stages: int) -> None:
+    def _post(self, stages: int, obs_noise=None) -> None:
         p, s, b = self._params(), self._state(), self._buffers()
-        rc = _lib.load().oige_hand_post_physics(C.byref(p), C.byref(s), C.byref(b), self._num_envs, stages,
-                                                _lib.current_stream(self.obs_buf.device))
-        _lib.check(rc, "oige_hand_post_physics")
+        if obs_noise is not None:
+            rc = _lib.load().oige_hand_post_physics_dr(C.byref(p), C.byref(s), C.byref(b), C.byref(obs_noise), self._num_envs,
+                                                       stages, _lib.current_stream(self.obs_buf.device))
+            _lib.check(rc, "oige_hand_post_physics_dr")
+        else:
+            rc = _lib.load().oige_hand_post_physics(C.byref(p), C.byref(s), C.byref(b), self._num_envs, stages,
+                                                    _lib.current_stream(self.obs_buf.device))
+            _lib.check(rc, "oige_hand_post_physics")
         if stages & _lib.STAGE_METRICS:
             self._counts_key = (self.reset_buf.data_ptr(), self.reset_buf._version,
                                 self.reset_goal_buf.data_ptr(), self.reset_goal_buf._version)
@@ -266,11 +271,20 @@ class InHandManipulationTask(RLTask):
     def is_done(self):
         pass
 
-    def post_physics_step(self):
+    @property
+    def supports_fused_dr(self) -> bool:
+        """True when post/pre_physics_step can apply the wrapper's observation / action noise inside their own kernels."""
+        return self.fused and self.sync_free and self.num_fingertips > 0
+
+    def post_physics_step(self, obs_noise=None):
+        """``obs_noise``: a NoiseArgs block (Randomizer.fused_observations_args) -> the observation noise and the clamped
+        copy of vec_env_rlgames.py:94-97 + :40 are produced while the obs tile streams out of the kernel."""
         if not self.fused:
+            if obs_noise is not None:
+                raise _lib.OigeError("post_physics_step(obs_noise=...) needs task.fused")
             return RLTask.post_physics_step(self)
         if self._env.world.is_playing():
-            self._post(_lib.STAGE_PROGRESS | _lib.STAGE_OBS | _lib.STAGE_METRICS)
+            self._post(_lib.STAGE_PROGRESS | _lib.STAGE_OBS | _lib.STAGE_METRICS, obs_noise)
             self._after_metrics()
         else:
             self.progress_buf[:] += 1
@@ -316,9 +330,13 @@ class InHandManipulationTask(RLTask):
         self._hands.set_joint_positions(o["dof_pos"][sl], **kw)
         self._hands.set_joint_velocities(o["dof_vel"][sl], **kw)
 
-    def pre_physics_step(self, actions):
+    def pre_physics_step(self, actions, action_noise=None):
+        """``action_noise``: a NoiseArgs block over ``actions`` (Randomizer.fused_actions_args) -> the action noise of
+        vec_env_rlgames.py:72-75 is applied while the kernel reads the actions (sync-free flow only)."""
         if not self.world.is_playing():
             return
+        if action_noise is not None and not self.sync_free:
+            raise _lib.OigeError("pre_physics_step(action_noise=...) needs task.sync_free")
         n = self._num_envs
         actions = actions.to(self.device)
         _lib.require_device_tensor(actions, torch.float32, (n, self._num_actions), "actions")
@@ -343,10 +361,16 @@ class InHandManipulationTask(RLTask):
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS  # the wrapper's clamp (vec_env_rlgames.py:77), folded into the kernel
         p, b, r = self._params(), self._buffers(), self._reset_io()
-        rc = _lib.load().oige_hand_pre_physics(
-            C.byref(p), actions.data_ptr(), C.byref(b), C.byref(r), self.actions.data_ptr(), self._targets_out.data_ptr(),
-            n, flags, _lib.current_stream(self.obs_buf.device))
-        _lib.check(rc, "oige_hand_pre_physics")
+        if action_noise is not None:
+            rc = _lib.load().oige_hand_pre_physics_dr(
+                C.byref(p), actions.data_ptr(), C.byref(b), C.byref(r), C.byref(action_noise), self.actions.data_ptr(),
+                self._targets_out.data_ptr(), n, flags, _lib.current_stream(self.obs_buf.device))
+            _lib.check(rc, "oige_hand_pre_physics_dr")
+        else:
+            rc = _lib.load().oige_hand_pre_physics(
+                C.byref(p), actions.data_ptr(), C.byref(b), C.byref(r), self.actions.data_ptr(), self._targets_out.data_ptr(),
+                n, flags, _lib.current_stream(self.obs_buf.device))
+            _lib.check(rc, "oige_hand_pre_physics")
         self._counts_key = None
         if self.sync_free:
             self._apply_goal_writes(None)

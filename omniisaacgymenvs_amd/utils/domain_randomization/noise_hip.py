@@ -64,6 +64,31 @@ class NoiseState:
         self.interval_workspace = _lib.new_workspace(n, device)
 
 
+def build_args(buffer: torch.Tensor, reset_buf: Optional[torch.Tensor], counter: torch.Tensor, correlated: torch.Tensor,
+               params: Dict[str, Any], seed: int, stream_id: int, step: int, clamped_out: Optional[torch.Tensor] = None,
+               clip: float = math.inf) -> _lib.NoiseArgs:
+    """The argument block of the in-kernel-Philox flow; also what the in-hand kernels take to apply the noise themselves
+    (``oige_hand_post_physics_dr`` / ``oige_hand_pre_physics_dr``: they hold the reset flags in registers, ``reset_buf`` is
+    not read and may be None)."""
+    n, w = buffer.shape
+    rq = _lib.require_device_tensor
+    rq(buffer, torch.float32, (n, w), "noise buffer")
+    rq(counter, torch.int32, (n,), "counter buffer")
+    rq(correlated, torch.float32, (n, w), "correlated noise buffer")
+    a = _lib.NoiseArgs()
+    a.buffer, a.counter, a.correlated_noise = buffer.data_ptr(), counter.data_ptr(), correlated.data_ptr()
+    if reset_buf is not None:
+        rq(reset_buf, torch.int64, (n,), "reset_buf")
+        a.reset_buf = reset_buf.data_ptr()
+    if clamped_out is not None:
+        rq(clamped_out, torch.float32, (n, w), "clamped_out")
+        a.clamped_out = clamped_out.data_ptr()
+        a.clip = float(min(clip, 3.0e38))
+    a.seed, a.step, a.stream_id, a.width = int(seed) & 0xFFFFFFFFFFFFFFFF, int(step), int(stream_id), int(w)
+    a.on_reset, a.on_interval = _term(params, "on_reset"), _term(params, "on_interval")
+    return a
+
+
 def apply(buffer: torch.Tensor, reset_buf: torch.Tensor, counter: torch.Tensor, correlated: torch.Tensor,
           params: Dict[str, Any], state: NoiseState, seed: int, stream_id: int, step: int, sync_free: bool = True,
           clamped_out: Optional[torch.Tensor] = None, clip: float = math.inf) -> torch.Tensor:

@@ -104,6 +104,25 @@ class Randomizer:
             stream_id=0, step=self._observations_step, sync_free=self.sync_free, clamped_out=clamped_out, clip=clip,
         )
 
+    # The in-hand kernels apply the noise in their own epilogue / prologue: these hand them the
+    # argument block, advancing the same step counter the separate launch would, so both flows draw the same samples.
+    def fused_observations_args(self, observations, clamped_out=None, clip=float("inf")):
+        from . import noise_hip
+
+        self._observations_step += 1
+        return noise_hip.build_args(
+            observations, None, self._observations_counter_buffer, self._observations_correlated_noise,
+            self._observations_dr_params, seed=int(self._config.get("seed", 0)), stream_id=0, step=self._observations_step,
+            clamped_out=clamped_out, clip=clip)
+
+    def fused_actions_args(self, actions):
+        from . import noise_hip
+
+        self._actions_step += 1
+        return noise_hip.build_args(
+            actions, None, self._actions_counter_buffer, self._actions_correlated_noise, self._actions_dr_params,
+            seed=int(self._config.get("seed", 0)), stream_id=1, step=self._actions_step)
+
     def apply_actions_randomization(self, actions, reset_buf, clamped_out=None, clip=float("inf")):
         from . import noise_hip
 

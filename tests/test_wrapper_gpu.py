@@ -18,13 +18,13 @@ from test_hand_gpu import _oracle_buffers, _oracle_state, _spec
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("fused_io", [True, False])
-def test_shadow_hand_step_with_dr_noise_matches_reference_sequence(fused_io):
+@pytest.mark.parametrize("fused_io,fused_dr", [(True, True), (True, False), (False, False)])
+def test_shadow_hand_step_with_dr_noise_matches_reference_sequence(fused_io, fused_dr):
     n = 600
     dr = copy.deepcopy(TASK_DEFAULTS["ShadowHandOpenAI_FF"]["domain_randomization"])
     dr["randomize"] = True
     env, task = make_task("ShadowHandOpenAI_FF", n, domain_randomization=dr)
-    env.fused_io = fused_io
+    env.fused_io, env.fused_dr = fused_io, fused_dr
     st = workloads.hand_state(n, task._env_pos.cpu(), task.goal_pos.cpu(), task.hand_dof_lower_limits.cpu(),
                               task.hand_dof_upper_limits.cpu(), device="cpu", seed=7)
     workloads.load_hand_state(task, st)
@@ -99,3 +99,36 @@ def test_ant_step_clamps_actions_in_kernel(fused_io):
         assert obs_dict["obs"].data_ptr() == task.obs_buf.data_ptr()  # clip_obs = inf: no copy
     else:
         assert obs_dict["obs"].data_ptr() != task.obs_buf.data_ptr()
+
+
+@pytest.mark.parametrize("cfg,n", [("ShadowHandOpenAI_FF", 600), ("ShadowHand", 257), ("ShadowHandOpenAI_FF", 4096)])
+def test_in_kernel_dr_noise_is_bit_identical_to_the_separate_launch(cfg, n):
+    """fused_dr (noise applied inside hand_pre / hand_post) against the oige_dr_noise_apply launches: same Philox keys,
+    same arithmetic -> identical bits in everything the step leaves behind."""
+    dr = copy.deepcopy(TASK_DEFAULTS[cfg]["domain_randomization"])
+    dr["randomize"] = True
+    runs = []
+    for fused_dr in (True, False):
+        torch.manual_seed(123)  # post_reset draws its initial DOF state from torch's generator
+        env, task = make_task(cfg, n, domain_randomization=dr, seed=11)
+        env.fused_dr = fused_dr
+        st = workloads.hand_state(n, task._env_pos.cpu(), task.goal_pos.cpu(), task.hand_dof_lower_limits.cpu(),
+                                  task.hand_dof_upper_limits.cpu(), device="cpu", seed=7)
+        workloads.load_hand_state(task, st)
+        for v in (task._hands, task._objects, task._goals):
+            v.apply_resets = False
+        g = torch.Generator().manual_seed(5)
+        out = []
+        for it in range(3):
+            actions = (torch.rand(n, 20, generator=g) * 3 - 1.5).to(task.device)
+            obs_dict, rew, resets, _ = env.step(actions)
+            r = task._dr_randomizer
+            out.append([t.clone() for t in (obs_dict["obs"], obs_dict["states"], rew, resets, task.obs_buf, task.actions, actions,
+                                            task.cur_targets, r._observations_correlated_noise, r._actions_correlated_noise,
+                                            r._observations_counter_buffer, r._actions_counter_buffer)])
+        torch.cuda.synchronize()
+        runs.append(out)
+    for it, (a, b) in enumerate(zip(*runs)):
+        for k, (x, y) in enumerate(zip(a, b)):
+            assert torch.equal(x, y), f"step {it} item {k}"
+    assert float(runs[0][-1][8].abs().max()) > 0  # the correlated noise was refreshed at least once
