@@ -10,6 +10,9 @@ run time and executed under local CPU torch by oracle/ref_exec.py:
     (tasks/cartpole.py:124-164) -> these outputs are PINNED by the reference;
   * get_observations (locomotion.py:224-284) runs verbatim ON TOP OF the restated omni helpers
     (oracle/torch_utils.py) -> composition pinned, helper layer UNPINNED.
+  * the in-hand family (ShadowHand, AllegroHand), Anymal (flat) and AnymalTerrain: the reference's METHODS run on a stub
+    ``self`` (the stubs of tests/test_oracle_pinned_*.py), torch's RNG replayed from a recorded seed; every input, every
+    output and the draws themselves are stored (the AnymalTerrain heightfield is regenerated from its seed: 4.8 MB).
 Only data is written (inputs + expected outputs); no reference text is stored.
 """
 from __future__ import annotations
@@ -177,9 +180,148 @@ def cartpole_golden(n: int, seed: int):
     )
 
 
+def _tests_on_path():
+    import sys
+
+    tests = os.path.join(os.path.dirname(OUT))
+    if tests not in sys.path:
+        sys.path.insert(0, tests)
+
+
+def _flat(prefix: str, obj) -> dict:
+    """dataclass / dict of tensors -> {prefix_field: ndarray} (None fields skipped, dict fields one level deep)."""
+    out = {}
+    items = obj.items() if isinstance(obj, dict) else obj.__dict__.items()
+    for k, v in items:
+        if isinstance(v, torch.Tensor):
+            out[f"{prefix}_{k}"] = v.detach().clone().numpy()
+        elif isinstance(v, dict):
+            for kk, vv in v.items():
+                if isinstance(vv, torch.Tensor):
+                    out[f"{prefix}_{k}__{kk}"] = vv.detach().clone().numpy()
+    return out
+
+
+def hand_golden(kind: str, n: int, seed: int):
+    """ShadowHand / AllegroHand: post_physics_step (progress += 1, get_observations, calculate_metrics) and
+    pre_physics_step, each from the same inputs, run from the reference's method source."""
+    _tests_on_path()
+    import test_oracle_pinned_hand as ph
+
+    spec = ph.SPECS[kind]()
+    s, b, init = ph._inputs(spec, n, seed)
+    data = {}
+    data.update(_flat("s", s))
+    data.update(_flat("b", b))
+    data.update(_flat("init", init))
+    ref = ph._stub(spec, s, b, init)
+    ref.progress_buf[:] += 1  # rl_task.py:289
+    ref.get_observations()
+    ref.calculate_metrics()
+    for k in ("obs_buf", "states_buf", "rew_buf", "reset_buf", "reset_goal_buf", "progress_buf", "successes", "consecutive_successes"):
+        data[f"post_{k}"] = getattr(ref, k).detach().clone().numpy()
+    # pre_physics_step from the same inputs, torch's generator seeded; the draws are recorded in the reference's order
+    ref = ph._stub(spec, s, b, init)
+    actions = torch.rand(n, spec.num_actions, generator=torch.Generator().manual_seed(seed + 50)) * 2 - 1
+    ng, ne = int((b.reset_goal_buf != 0).sum()), int((b.reset_buf != 0).sum())
+    torch.manual_seed(seed + 100)
+    ref.pre_physics_step(actions.clone())
+    torch.manual_seed(seed + 100)
+    u_goal = 2.0 * torch.rand(ng, 4) + (-1.0)
+    u_reset = 2.0 * torch.rand(ne, 2 * spec.num_hand_dofs + 5) + (-1.0)
+    u_reset_goal = 2.0 * torch.rand(ne, 4) + (-1.0)
+    data.update(pre_actions=actions.numpy(), pre_u_goal=u_goal.numpy(), pre_u_reset=u_reset.numpy(), pre_u_reset_goal=u_reset_goal.numpy())
+    for k in ("reset_buf", "reset_goal_buf", "progress_buf", "successes", "goal_pos", "goal_rot", "actions", "prev_targets", "cur_targets"):
+        data[f"pre_{k}"] = getattr(ref, k).detach().clone().numpy()
+    h, ob, gl = ref._hands.calls, ref._objects.calls, ref._goals.calls
+    data.update(pre_targets=h["targets"].numpy(), pre_dof_pos=h["q"].numpy(), pre_dof_vel=h["qd"].numpy(),
+                pre_object_pos=ob["poses"][0][0].numpy(), pre_object_rot=ob["poses"][0][1].numpy(),
+                pre_goal_world_pos=gl["poses"][0][0].numpy(), pre_goal_rot_rows=gl["poses"][0][1].numpy(),
+                pre_r_goal_world_pos=gl["poses"][1][0].numpy(), pre_r_goal_rot=gl["poses"][1][1].numpy())
+    return data
+
+
+def anymal_flat_golden(n: int, seed: int):
+    _tests_on_path()
+    import test_oracle_pinned_anymal_flat as pf
+
+    spec, st, b, lower, upper = pf._inputs(n, seed)
+    data = {f"st_{k}": v.numpy() for k, v in st.items()}
+    data.update(_flat("b", b))
+    data.update(lower=lower.numpy(), upper=upper.numpy())
+    ref = pf._stub(spec, st, b, lower, upper)
+    ref.progress_buf[:] += 1
+    ref.get_observations()
+    ref.calculate_metrics()
+    ref.is_done()
+    for k in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "last_actions", "last_dof_vel"):
+        data[f"post_{k}"] = getattr(ref, k).detach().clone().numpy()
+    ref = pf._stub(spec, st, b, lower, upper)
+    actions = torch.rand(n, 12, generator=torch.Generator().manual_seed(seed + 50)) * 2 - 1
+    k = int((b.reset_buf != 0).sum())
+    torch.manual_seed(seed + 100)
+    ref.pre_physics_step(actions.clone())
+    torch.manual_seed(seed + 100)
+    draws = [torch.rand(k, 12), torch.rand(k, 1), torch.rand(k, 1), torch.rand(k, 1)]
+    data.update(pre_actions=actions.numpy(), pre_initial_root_pos=ref.initial_root_pos.numpy(),
+                pre_initial_root_rot=ref.initial_root_rot.numpy(), **{f"pre_u{i}": d.numpy() for i, d in enumerate(draws)})
+    for kk in ("reset_buf", "progress_buf", "commands", "actions", "last_actions", "last_dof_vel", "current_targets"):
+        data[f"pre_{kk}"] = getattr(ref, kk).detach().clone().numpy()
+    c = ref._anymals.calls
+    data.update(pre_dof_pos=c["q"].numpy(), pre_dof_vel=c["qd"].numpy(), pre_root_vel=c["vel"].numpy(),
+                pre_root_pos=c["pose"][0].numpy(), pre_root_rot=c["pose"][1].numpy())
+    return data
+
+
+def anymal_terrain_golden(n: int, seed: int):
+    """AnymalTerrain post_physics_step from the reference's method source.  The (1200, 2000) int16 heightfield is not
+    stored: it is the first draw of torch.Generator().manual_seed(seed) (``hs_sum`` guards the regeneration)."""
+    _tests_on_path()
+    import test_oracle_pinned_anymal as pa
+    from . import anymal_terrain_oracle as ao
+
+    spec, s, b, hs, origins = pa._make_inputs(n, seed)
+    data = {}
+    data.update(_flat("s", s))
+    data.update(_flat("b", b))
+    data.update(origins=origins.numpy(), hs_sum=np.array(int(hs.long().sum())), hs_seed=np.array(seed))
+    ref = pa._reference_stub(spec, s, b, hs, origins)
+    torch.manual_seed(1000 + seed)
+    ref.post_physics_step()
+    k = int(ref.extras["episode"]["terrain_level"].numel() and len([c for c in ref._anymals.calls if c[0] == "q"][0][1]))
+    torch.manual_seed(1000 + seed)
+    draws = [torch.rand(k, 12), torch.rand(k, 12), torch.rand(k, 2), torch.rand(k, 1), torch.rand(k, 1), torch.rand(k, 1)]
+    noise_u = torch.rand(n, 188)  # rand_like(obs_buf), drawn after the reset draws (:438)
+    data.update(noise_u=noise_u.numpy(), **{f"draw{i}": d.numpy() for i, d in enumerate(draws)})
+    for kk in ("obs_buf", "rew_buf", "reset_buf", "timeout_buf", "progress_buf", "commands", "last_actions", "last_dof_vel",
+               "feet_air_time", "terrain_levels", "env_origins"):
+        data[f"post_{kk}"] = getattr(ref, kk).detach().clone().numpy()
+    for kk in ao.EPISODE_KEYS:
+        data[f"post_episode_sums__{kk}"] = ref.episode_sums[kk].numpy()
+        data[f"post_extras__{kk}"] = ref.extras["episode"]["rew_" + kk].numpy()
+    data["post_extras__terrain_level"] = ref.extras["episode"]["terrain_level"].numpy()
+    calls = {c[0]: c for c in ref._anymals.calls}
+    data.update(reset_base_pos=calls["poses"][1].numpy(), reset_base_quat=calls["poses"][2].numpy(),
+                reset_dof_pos=calls["q"][1].numpy(), reset_dof_vel=calls["qd"][1].numpy(), reset_base_vel=calls["vel"][1].numpy())
+    return data
+
+
 def main() -> None:
     assert ref_exec.available(), "needs /root/reference (run in the build container)"
     os.makedirs(OUT, exist_ok=True)
+    for kind in ("shadow_openai_ff", "shadow_full", "allegro_full", "allegro_mcs_ema"):
+        for n, seed in ((64, 0), (257, 1)):
+            path = os.path.join(OUT, f"hand_{kind}_n{n}_s{seed}.npz")
+            np.savez_compressed(path, **hand_golden(kind, n, seed))
+            print("wrote", path, os.path.getsize(path), "bytes")
+    for n, seed in ((64, 0), (257, 1)):
+        path = os.path.join(OUT, f"anymalflat_n{n}_s{seed}.npz")
+        np.savez_compressed(path, **anymal_flat_golden(n, seed))
+        print("wrote", path, os.path.getsize(path), "bytes")
+    for n, seed in ((40, 0), (257, 1)):
+        path = os.path.join(OUT, f"anymalterrain_n{n}_s{seed}.npz")
+        np.savez_compressed(path, **anymal_terrain_golden(n, seed))
+        print("wrote", path, os.path.getsize(path), "bytes")
     for kind in ("ant", "humanoid"):
         for n, seed in ((64, 0), (257, 1)):
             path = os.path.join(OUT, f"{kind}_n{n}_s{seed}.npz")

@@ -26,3 +26,26 @@ def spec_for(kind: str, g) -> lo.LocomotionSpec:
     spec.dof_limits_lower, spec.dof_limits_upper = g["lo"], g["hi"]
     spec.joint_gears, spec.motor_effort_ratio = g["gears"], g["motor_effort_ratio"]
     return spec
+
+
+def unflat(g, prefix: str, cls=None):
+    """Inverse of oracle/gen_golden._flat: {prefix_field: tensor} -> cls(**fields) (missing fields None) or a dict."""
+    import dataclasses
+
+    p = prefix + "_"
+    d = {}
+    for k, v in g.items():
+        if not k.startswith(p):
+            continue
+        name = k[len(p):]
+        if "__" in name:
+            a, b = name.split("__", 1)
+            d.setdefault(a, {})[b] = v.clone()
+        else:
+            d[name] = v.clone()
+    if cls is None:
+        return d
+    for f in dataclasses.fields(cls):
+        if f.default is dataclasses.MISSING and f.default_factory is dataclasses.MISSING:
+            d.setdefault(f.name, None)
+    return cls(**d)
