@@ -72,3 +72,21 @@ def test_product_path_never_imports_the_oracle():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_every_entry_point_rejects_null_arguments_without_touching_the_gpu():
+    """All-NULL / zero arguments: every compute entry point must come back with a negative code and a message (never a
+    crash, never a launch).  Validation runs before any HIP call, so this is safe without a device."""
+    lib = _lib.load()
+    pure = {"oige_version", "oige_num_tiles", "oige_workspace_ints", "oige_last_error"}
+    checked = 0
+    for name, (res, args) in _lib.SIGNATURES.items():
+        if name in pure:
+            continue
+        argv = [None if (a is _lib._P or (isinstance(a, type) and issubclass(a, ctypes._Pointer))) else 0 for a in args]
+        rc = getattr(lib, name)(*argv)
+        assert rc < 0, f"{name} accepted NULL arguments (rc={rc})"
+        msg = lib.oige_last_error()
+        assert msg and len(msg) > 5, name
+        checked += 1
+    assert checked >= 20
