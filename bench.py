@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- fused obs+reward+reset env-steps/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter]
 
 One "step" = one pre_physics_step (reset-id compaction, reset of the flagged envs, action scaling /
 PD torques) + one post_physics_step (progress, obs, reward, done[, in-step reset]) over a batch of
@@ -315,6 +315,55 @@ class AllegroHandBench:
         return step
 
 
+class QuadcopterBench:
+    """Quadcopter obs(21) + inverse-quadratic reward + non-sticky done, targets / thrust integration."""
+
+    def __init__(self, name, n, dev, seed):
+        from helpers import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+
+        self.env, self.task = make_task("Quadcopter", n, device=dev, seed=seed)
+        t = self.task
+        st = workloads.quadcopter_state(n, t._env_pos, device=dev, seed=seed)
+        workloads.load_quadcopter_state(t, st)
+        t._copters.apply_resets = False
+        self.actions = st["actions"]
+        self.post_bytes = 116 + 104  # csrc/quadcopter.hip header
+        self.kernel = "quadcopter_post_kernel"
+        self.workload = f"Quadcopter obs(21)+reward+reset fused, {n} envs per GPU, synthetic root/DOF state"
+        self.extra_cfg = {"num_dof": 8}
+
+    def pre(self):
+        self.task.pre_physics_step(self.actions)
+
+    def post(self):
+        self.task.post_physics_step()
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from oracle import quadcopter_oracle as qo
+
+        spec = qo.QuadcopterSpec()
+        env_pos = torch.zeros(n, 3)
+        st = workloads.quadcopter_state(n, env_pos, device="cpu", seed=1234)
+        tp = torch.zeros(n, 3)
+        tp[:, 2] = 1.0
+        b = qo.QuadcopterBuffers(torch.zeros(n, 21), torch.zeros(n), st["reset"].clone(), st["progress"].clone(), tp,
+                                 st["targets"].clone(), st["thrusts"].clone(), torch.zeros(n, 4, 3))
+        init_pos, init_rot = st["root_pos"].clone(), st["root_rot"].clone()
+        draw = lambda ids: (torch.rand(len(ids), 8), torch.rand(len(ids), 1), torch.rand(len(ids), 1), torch.rand(len(ids), 1))
+
+        def step():
+            qo.pre_physics(spec, b, st["actions"], init_pos, init_rot, draw)
+            qo.post_physics(spec, b, st["root_pos"], st["root_rot"], st["root_vel"], st["dof_pos"], env_pos)
+
+        return step
+
+
 class AnymalFlatBench:
     """Anymal on flat ground (obs 48, 6-term reward, non-sticky done, position targets)."""
 
@@ -363,9 +412,9 @@ class AnymalFlatBench:
         return step
 
 
-ADAPTERS = {"AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
-DEFAULT_ENVS = {"AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
-CPU_ENVS = {"AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
+ADAPTERS = {"Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
+DEFAULT_ENVS = {"Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
+CPU_ENVS = {"Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
 def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:

@@ -559,6 +559,77 @@ int oige_hand_pre_physics_dr(const oige_hand_params* params, float* actions_inou
                              const oige_noise_args* action_noise, float* actions_out, float* targets_out,
                              int64_t num_envs, uint32_t flags, oige_stream_t stream);
 
+/* ------------------------------------------------------------------ Quadcopter
+ * tasks/quadcopter.py.  Scalars: cfg/task/Quadcopter.yaml:7-17, quadcopter.py:46-55,153-161.                  */
+#define OIGE_QUAD_DOFS 8
+#define OIGE_QUAD_OBS 21
+#define OIGE_QUAD_ACTIONS 12
+
+typedef struct oige_quadcopter_params {
+  float dof_rate;             /* (float)(dt * 8 pi): self.dt * dof_action_speed_scale, folded in double as Python does (:153-154) */
+  float thrust_rate;          /* (float)(dt * 100) (:159-160) */
+  float max_thrust;           /* 2.0 (:53-55) */
+  float clip_actions;         /* with OIGE_PRE_CLAMP_ACTIONS */
+  int32_t max_episode_length; /* 500 */
+  int32_t reserved0[3];
+  float dof_lower[OIGE_QUAD_DOFS];
+  float dof_upper[OIGE_QUAD_DOFS];
+} oige_quadcopter_params;
+
+typedef struct oige_quadcopter_state {  /* view getters of get_observations (:125-127), world frame, read-only */
+  const float* root_pos;        /* (N,3) */
+  const float* root_rot;        /* (N,4) wxyz */
+  const float* root_velocities; /* (N,6) */
+  const float* dof_pos;         /* (N,8) */
+  const float* env_pos;         /* (N,3) RLTask._env_pos */
+} oige_quadcopter_state;
+
+typedef struct oige_quadcopter_buffers {
+  float* obs_buf;                /* (N,21) */
+  float* rew_buf;                /* (N,) */
+  int64_t* reset_buf;            /* (N,) */
+  int64_t* progress_buf;         /* (N,) */
+  const float* target_positions; /* (N,3) (:190-191) */
+  float* dof_position_targets;   /* (N,8) */
+  float* thrusts;                /* (N,4) */
+  float* forces;                 /* (N,4,3): only the z components are written, all three zeroed on reset (:163-170) */
+  int32_t* reset_workspace;      /* as oige_locomotion_buffers.reset_workspace */
+} oige_quadcopter_buffers;
+
+/* post_physics_step: progress += 1, get_observations (:124-141), calculate_metrics (:229-251), is_done (:253-261, NOT
+ * sticky).  `stages` as for locomotion.                                                                         */
+int oige_quadcopter_post_physics(const oige_quadcopter_params* params, const oige_quadcopter_state* state,
+                                 const oige_quadcopter_buffers* buffers, int64_t num_envs, uint32_t stages,
+                                 oige_stream_t stream);
+
+typedef struct oige_quadcopter_reset_io {
+  const float* initial_root_pos; /* (N,3) (:197) */
+  const float* initial_root_rot; /* (N,4) */
+  const float* u_dof;            /* NULL, or (n,8) pre-drawn U[0,1): the draw of :206 */
+  const float* u_xyz;            /* NULL, or (n,3): the three (n,1) draws of :210-212, one per column */
+  uint64_t seed;
+  uint64_t step;
+  int64_t* env_ids;              /* out (N,) ascending == reset_buf.nonzero() */
+  int64_t* count;                /* out device scalar */
+  float* dof_pos_out;            /* out (n,8) */
+  float* dof_vel_out;            /* out (n,8) zeros */
+  float* root_pos_out;           /* out (n,3) */
+  float* root_rot_out;           /* out (n,4) */
+  float* root_vel_out;           /* out (n,6) zeros */
+} oige_quadcopter_reset_io;
+
+/* pre_physics_step (:143-175): compaction, reset_idx of the flagged envs, DOF-target and thrust integration + clamps, z
+ * forces; reset envs end with thrusts = forces = 0 and targets = their re-drawn DOF positions.  The reference keeps no
+ * clone of the actions on the task, so there is no actions_out.                                                   */
+int oige_quadcopter_pre_physics(const oige_quadcopter_params* params, const float* actions_in,
+                                const oige_quadcopter_buffers* buffers, const oige_quadcopter_reset_io* reset_io,
+                                int64_t num_envs, uint32_t flags, oige_stream_t stream);
+
+/* reset_idx(env_ids) with caller-provided ids (:203-227).                                                         */
+int oige_quadcopter_reset_idx(const oige_quadcopter_params* params, const oige_quadcopter_buffers* buffers,
+                              const oige_quadcopter_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                              oige_stream_t stream);
+
 /* ------------------------------------------------------------------ Cartpole
  * tasks/cartpole.py:91-164.                                                                 */
 typedef struct oige_cartpole_params {

@@ -180,6 +180,26 @@ class AnymalFlatResetIO(C.Structure):
                 ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp)]
 
 
+class QuadcopterParams(C.Structure):
+    _fields_ = [("dof_rate", _f), ("thrust_rate", _f), ("max_thrust", _f), ("clip_actions", _f),
+                ("max_episode_length", C.c_int32), ("reserved0", C.c_int32 * 3), ("dof_lower", _f * 8), ("dof_upper", _f * 8)]
+
+
+class QuadcopterState(C.Structure):
+    _fields_ = [(n, _fp) for n in ("root_pos", "root_rot", "root_velocities", "dof_pos", "env_pos")]
+
+
+class QuadcopterBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "target_positions",
+                                   "dof_position_targets", "thrusts", "forces", "reset_workspace")]
+
+
+class QuadcopterResetIO(C.Structure):
+    _fields_ = [("initial_root_pos", _fp), ("initial_root_rot", _fp), ("u_dof", _fp), ("u_xyz", _fp), ("seed", C.c_uint64),
+                ("step", C.c_uint64), ("env_ids", _fp), ("count", _fp), ("dof_pos_out", _fp), ("dof_vel_out", _fp),
+                ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp)]
+
+
 NOISE_ADDITIVE, NOISE_SCALING = 0, 1
 NOISE_GAUSSIAN, NOISE_UNIFORM, NOISE_LOGUNIFORM = 0, 1, 2
 
@@ -236,6 +256,12 @@ SIGNATURES = {
                                                C.POINTER(AnymalFlatResetIO), _P, C.c_int64, C.c_uint32, _P]),
     "oige_anymal_flat_reset_idx": (C.c_int, [C.POINTER(AnymalFlatParams), C.POINTER(AnymalFlatBuffers),
                                              C.POINTER(AnymalFlatResetIO), C.c_int64, C.c_int64, _P]),
+    "oige_quadcopter_post_physics": (C.c_int, [C.POINTER(QuadcopterParams), C.POINTER(QuadcopterState),
+                                               C.POINTER(QuadcopterBuffers), C.c_int64, C.c_uint32, _P]),
+    "oige_quadcopter_pre_physics": (C.c_int, [C.POINTER(QuadcopterParams), _P, C.POINTER(QuadcopterBuffers),
+                                              C.POINTER(QuadcopterResetIO), C.c_int64, C.c_uint32, _P]),
+    "oige_quadcopter_reset_idx": (C.c_int, [C.POINTER(QuadcopterParams), C.POINTER(QuadcopterBuffers),
+                                            C.POINTER(QuadcopterResetIO), C.c_int64, C.c_int64, _P]),
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "oige_dr_noise_count": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_dr_noise_apply": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),

@@ -222,3 +222,34 @@ def load_anymal_flat_state(task, st: Dict[str, Tensor]) -> None:
     task.current_targets.copy_(st["current_targets"].to(dev))
     task.progress_buf.copy_(st["progress"].to(dev))
     task.reset_buf.copy_(st["reset"].to(dev))
+
+
+def quadcopter_state(n: int, env_pos: Tensor, device="cpu", seed: int = 1234) -> Dict[str, Tensor]:
+    """Quadcopter: root within ~1.2 m of the target at (0, 0, 1) (a few per cent beyond the 3 m / below
+    the 0.3 m reset thresholds), unit quaternions near upright, DOF positions in +-0.8, progress up to the 500-step episode."""
+    g = _gen(device, seed)
+    f = dict(device=device, dtype=torch.float32, generator=g)
+    env_pos = env_pos.to(device)
+    q = torch.randn(n, 4, **f) * 0.3
+    q[:, 0] += 1.0
+    q = (q / q.norm(dim=-1, keepdim=True)).contiguous()
+    off = torch.cat([torch.randn(n, 2, **f) * 1.2, torch.rand(n, 1, **f) * 1.9 + 0.2], -1)
+    return dict(
+        root_pos=(env_pos + off).contiguous(), root_rot=q, root_vel=torch.randn(n, 6, **f) * 2.0,
+        dof_pos=torch.rand(n, 8, **f) * 1.6 - 0.8, actions=torch.rand(n, 12, **f) * 2.0 - 1.0,
+        targets=torch.rand(n, 8, **f) * 1.6 - 0.8, thrusts=torch.rand(n, 4, **f) * 4.0 - 2.0,
+        progress=torch.randint(0, 500, (n,), device=device, generator=g, dtype=torch.int64),
+        reset=(torch.rand(n, **f) < 0.05).long(),
+    )
+
+
+def load_quadcopter_state(task, st: Dict[str, Tensor]) -> None:
+    dev, v = task.device, task._copters
+    v.positions.copy_(st["root_pos"].to(dev))
+    v.orientations.copy_(st["root_rot"].to(dev))
+    v.velocities.copy_(st["root_vel"].to(dev))
+    v.joint_positions.copy_(st["dof_pos"].to(dev))
+    task.dof_position_targets.copy_(st["targets"].to(dev))
+    task.thrusts.copy_(st["thrusts"].to(dev))
+    task.progress_buf.copy_(st["progress"].to(dev))
+    task.reset_buf.copy_(st["reset"].to(dev))

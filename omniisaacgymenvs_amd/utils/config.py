@@ -118,6 +118,14 @@ _ALLEGRO_HAND_ENV = {k: v for k, v in _SHADOW_HAND_ENV.items()
 _ALLEGRO_HAND_ENV.update({"controlFrequencyInv": 4})
 TASK_DEFAULTS["AllegroHand"] = {"name": "AllegroHand", "env": _ALLEGRO_HAND_ENV, "sim": dict(_SIM, dt=0.0083)}
 
+# cfg/task/Quadcopter.yaml:7-17
+TASK_DEFAULTS["Quadcopter"] = {
+    "name": "Quadcopter",
+    "env": {"numEnvs": 4096, "envSpacing": 1.25, "maxEpisodeLength": 500, "enableDebugVis": False,
+            "clipObservations": 5.0, "clipActions": 1.0},
+    "sim": dict(_SIM, dt=0.01),
+}
+
 # cfg/task/AnymalTerrain.yaml:5-103
 TASK_DEFAULTS["AnymalTerrain"] = {
     "name": "AnymalTerrain",

@@ -139,6 +139,17 @@ def quat_rotate(q: Tensor, v: Tensor) -> Tensor:
     return a + b + c
 
 
+def quat_axis(q: Tensor, axis: int = 0) -> Tensor:
+    """The body axis `axis` in the world frame: quat_rotate(q, e_axis).
+
+    Call sites: tasks/quadcopter.py:241, ingenuity.py:257, crazyflie.py (uprightness terms).  Restated from the public
+    IsaacGym torch_utils lineage (basis_vec = zeros(n, 3); basis_vec[:, axis] = 1; quat_rotate(q, basis_vec)): UNPINNED.
+    """
+    basis_vec = torch.zeros(q.shape[0], 3, device=q.device)
+    basis_vec[:, axis] = 1
+    return quat_rotate(q, basis_vec)
+
+
 def quat_rotate_inverse(q: Tensor, v: Tensor) -> Tensor:
     """Same three terms as :func:`quat_rotate` with the cross term subtracted.
 
@@ -225,6 +236,6 @@ def compute_rot(
 
 HELPER_NAMES = (
     "tensor_clamp scale unscale torch_rand_float normalize quat_mul quat_conjugate quat_apply "
-    "quat_rotate quat_rotate_inverse quat_from_angle_axis get_basis_vector copysign get_euler_xyz "
+    "quat_rotate quat_rotate_inverse quat_axis quat_from_angle_axis get_basis_vector copysign get_euler_xyz "
     "compute_heading_and_up compute_rot"
 ).split()
