@@ -630,6 +630,76 @@ int oige_quadcopter_reset_idx(const oige_quadcopter_params* params, const oige_q
                               const oige_quadcopter_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
                               oige_stream_t stream);
 
+/* ------------------------------------------------------------------ BallBalance
+ * tasks/ball_balance.py.  Scalars: cfg/task/BallBalance.yaml:7-13, ball_balance.py:58-71.                      */
+#define OIGE_BBOT_OBS 24
+#define OIGE_BBOT_MAX_DOFS 8
+
+typedef struct oige_ball_balance_params {
+  float rate;                   /* (float)(dt * actionSpeedScale), folded in double as Python does (:196-198) */
+  float ball_low;               /* (float)(ball_radius * 1.5) (:305) */
+  float clip_actions;           /* with OIGE_PRE_CLAMP_ACTIONS */
+  int32_t max_episode_length;   /* 600 */
+  int32_t num_dof;              /* row width of dof_pos / dof_vel / dof_position_targets (3..8) */
+  int32_t actuated_dof_indices[3]; /* lower_leg0..2 (:277-280) */
+  float dof_lower[OIGE_BBOT_MAX_DOFS];
+  float dof_upper[OIGE_BBOT_MAX_DOFS];
+} oige_ball_balance_params;
+
+typedef struct oige_ball_balance_state {  /* view getters of get_observations (:160-169), world frame, read-only */
+  const float* ball_pos;        /* (N,3) */
+  const float* ball_velocities; /* (N,6) */
+  const float* dof_pos;         /* (N,num_dof) */
+  const float* dof_vel;         /* (N,num_dof) */
+  const float* sensors;         /* (N,3,6) measured joint forces of upper_leg0..2 */
+  const float* env_pos;         /* (N,3) */
+} oige_ball_balance_state;
+
+typedef struct oige_ball_balance_buffers {
+  float* obs_buf;               /* (N,24) */
+  float* rew_buf;               /* (N,) */
+  int64_t* reset_buf;           /* (N,) */
+  int64_t* progress_buf;        /* (N,) */
+  float* dof_position_targets;  /* (N,num_dof) */
+  int32_t* reset_workspace;     /* as oige_locomotion_buffers.reset_workspace */
+} oige_ball_balance_buffers;
+
+/* post_physics_step: progress += 1, get_observations (:159-185), calculate_metrics (:286-299), is_done (:301-308, sticky). */
+int oige_ball_balance_post_physics(const oige_ball_balance_params* params, const oige_ball_balance_state* state,
+                                   const oige_ball_balance_buffers* buffers, int64_t num_envs, uint32_t stages,
+                                   oige_stream_t stream);
+
+typedef struct oige_ball_balance_reset_io {
+  const float* initial_ball_pos;       /* (N,3) post_reset constants (:266-272) */
+  const float* initial_bot_pos;        /* (N,3) */
+  const float* initial_bot_rot;        /* (N,4) */
+  const float* initial_bot_velocities; /* (N,6) */
+  const float* initial_dof_positions;  /* (N,num_dof) */
+  const float* u;                      /* NULL, or (n,5) pre-drawn U[0,1): dists, dirs, hspeeds, vspeeds, height (:220-232) */
+  uint64_t seed;
+  uint64_t step;
+  int64_t* env_ids;                    /* out (N,) ascending == reset_buf.nonzero() */
+  int64_t* count;                      /* out device scalar */
+  float* ball_pos_out;                 /* out (n,3) */
+  float* ball_rot_out;                 /* out (n,4) identity */
+  float* ball_vel_out;                 /* out (n,6) */
+  float* bot_pos_out;                  /* out (n,3) */
+  float* bot_rot_out;                  /* out (n,4) */
+  float* bot_vel_out;                  /* out (n,6) */
+  float* dof_pos_out;                  /* out (n,num_dof) */
+} oige_ball_balance_reset_io;
+
+/* pre_physics_step (:187-206): compaction, reset_idx of the flagged envs, integrate + clamp the position targets, zero
+ * the targets of the reset envs.                                                                                  */
+int oige_ball_balance_pre_physics(const oige_ball_balance_params* params, const float* actions_in,
+                                  const oige_ball_balance_buffers* buffers, const oige_ball_balance_reset_io* reset_io,
+                                  int64_t num_envs, uint32_t flags, oige_stream_t stream);
+
+/* reset_idx(env_ids) with caller-provided ids (:208-260).                                                         */
+int oige_ball_balance_reset_idx(const oige_ball_balance_params* params, const oige_ball_balance_buffers* buffers,
+                                const oige_ball_balance_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                                oige_stream_t stream);
+
 /* ------------------------------------------------------------------ Cartpole
  * tasks/cartpole.py:91-164.                                                                 */
 typedef struct oige_cartpole_params {

@@ -200,6 +200,26 @@ class QuadcopterResetIO(C.Structure):
                 ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp)]
 
 
+class BallBalanceParams(C.Structure):
+    _fields_ = [("rate", _f), ("ball_low", _f), ("clip_actions", _f), ("max_episode_length", C.c_int32), ("num_dof", C.c_int32),
+                ("actuated_dof_indices", C.c_int32 * 3), ("dof_lower", _f * 8), ("dof_upper", _f * 8)]
+
+
+class BallBalanceState(C.Structure):
+    _fields_ = [(n, _fp) for n in ("ball_pos", "ball_velocities", "dof_pos", "dof_vel", "sensors", "env_pos")]
+
+
+class BallBalanceBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "dof_position_targets", "reset_workspace")]
+
+
+class BallBalanceResetIO(C.Structure):
+    _fields_ = [(n, _fp) for n in ("initial_ball_pos", "initial_bot_pos", "initial_bot_rot", "initial_bot_velocities",
+                                   "initial_dof_positions", "u")] + [("seed", C.c_uint64), ("step", C.c_uint64)] + [
+        (n, _fp) for n in ("env_ids", "count", "ball_pos_out", "ball_rot_out", "ball_vel_out", "bot_pos_out", "bot_rot_out",
+                           "bot_vel_out", "dof_pos_out")]
+
+
 NOISE_ADDITIVE, NOISE_SCALING = 0, 1
 NOISE_GAUSSIAN, NOISE_UNIFORM, NOISE_LOGUNIFORM = 0, 1, 2
 
@@ -262,6 +282,12 @@ SIGNATURES = {
                                               C.POINTER(QuadcopterResetIO), C.c_int64, C.c_uint32, _P]),
     "oige_quadcopter_reset_idx": (C.c_int, [C.POINTER(QuadcopterParams), C.POINTER(QuadcopterBuffers),
                                             C.POINTER(QuadcopterResetIO), C.c_int64, C.c_int64, _P]),
+    "oige_ball_balance_post_physics": (C.c_int, [C.POINTER(BallBalanceParams), C.POINTER(BallBalanceState),
+                                                 C.POINTER(BallBalanceBuffers), C.c_int64, C.c_uint32, _P]),
+    "oige_ball_balance_pre_physics": (C.c_int, [C.POINTER(BallBalanceParams), _P, C.POINTER(BallBalanceBuffers),
+                                                C.POINTER(BallBalanceResetIO), C.c_int64, C.c_uint32, _P]),
+    "oige_ball_balance_reset_idx": (C.c_int, [C.POINTER(BallBalanceParams), C.POINTER(BallBalanceBuffers),
+                                              C.POINTER(BallBalanceResetIO), C.c_int64, C.c_int64, _P]),
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "oige_dr_noise_count": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_dr_noise_apply": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),

@@ -253,3 +253,31 @@ def load_quadcopter_state(task, st: Dict[str, Tensor]) -> None:
     task.thrusts.copy_(st["thrusts"].to(dev))
     task.progress_buf.copy_(st["progress"].to(dev))
     task.reset_buf.copy_(st["reset"].to(dev))
+
+
+def ball_balance_state(n: int, env_pos: Tensor, device="cpu", seed: int = 1234) -> Dict[str, Tensor]:
+    """BallBalance: ball within ~0.3 m of the tray centre, z in (0.05, 1.25) (~8 % below the 0.15 reset
+    height), 6 DOFs in +-1, force sensors N(0, 30), progress up to the 600-step episode."""
+    g = _gen(device, seed)
+    f = dict(device=device, dtype=torch.float32, generator=g)
+    env_pos = env_pos.to(device)
+    off = torch.cat([torch.randn(n, 2, **f) * 0.3, torch.rand(n, 1, **f) * 1.2 + 0.05], -1)
+    return dict(
+        ball_pos=(env_pos + off).contiguous(), ball_vel=torch.randn(n, 6, **f) * 1.5, dof_pos=torch.rand(n, 6, **f) * 2 - 1,
+        dof_vel=torch.randn(n, 6, **f), sensors=torch.randn(n, 3, 6, **f) * 30, actions=torch.rand(n, 3, **f) * 2.0 - 1.0,
+        targets=torch.rand(n, 6, **f) * 2.4 - 1.2,
+        progress=torch.randint(0, 600, (n,), device=device, generator=g, dtype=torch.int64),
+        reset=(torch.rand(n, **f) < 0.05).long(),
+    )
+
+
+def load_ball_balance_state(task, st: Dict[str, Tensor]) -> None:
+    dev = task.device
+    task._balls.positions.copy_(st["ball_pos"].to(dev))
+    task._balls.velocities.copy_(st["ball_vel"].to(dev))
+    task._balance_bots.joint_positions.copy_(st["dof_pos"].to(dev))
+    task._balance_bots.joint_velocities.copy_(st["dof_vel"].to(dev))
+    task._balance_bots.measured_joint_forces.copy_(st["sensors"].to(dev))
+    task.dof_position_targets.copy_(st["targets"].to(dev))
+    task.progress_buf.copy_(st["progress"].to(dev))
+    task.reset_buf.copy_(st["reset"].to(dev))

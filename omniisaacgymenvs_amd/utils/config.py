@@ -126,6 +126,14 @@ TASK_DEFAULTS["Quadcopter"] = {
     "sim": dict(_SIM, dt=0.01),
 }
 
+# cfg/task/BallBalance.yaml:7-13
+TASK_DEFAULTS["BallBalance"] = {
+    "name": "BallBalance",
+    "env": {"numEnvs": 4096, "envSpacing": 2.0, "maxEpisodeLength": 600, "actionSpeedScale": 20,
+            "clipObservations": 5.0, "clipActions": 1.0},
+    "sim": dict(_SIM, dt=0.01),
+}
+
 # cfg/task/AnymalTerrain.yaml:5-103
 TASK_DEFAULTS["AnymalTerrain"] = {
     "name": "AnymalTerrain",

@@ -139,6 +139,18 @@ def quat_rotate(q: Tensor, v: Tensor) -> Tensor:
     return a + b + c
 
 
+def random_dir_2_from_unit(u: Tensor) -> Tensor:
+    """torch_random_dir_2(shape, device) with its U[0,1) draw supplied: angle = torch_rand_float(-pi, pi, shape).squeeze(-1);
+    stack([cos(angle), sin(angle)], -1).  Call site: tasks/ball_balance.py:222.  Restated from the public IsaacGym
+    torch_utils lineage: UNPINNED."""
+    angle = ((math.pi - (-math.pi)) * u + (-math.pi)).squeeze(-1)
+    return torch.stack([torch.cos(angle), torch.sin(angle)], dim=-1)
+
+
+def torch_random_dir_2(shape, device="cpu") -> Tensor:
+    return random_dir_2_from_unit(torch.rand(*shape, device=device))
+
+
 def quat_axis(q: Tensor, axis: int = 0) -> Tensor:
     """The body axis `axis` in the world frame: quat_rotate(q, e_axis).
 
