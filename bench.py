@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- fused obs+reward+reset env-steps/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter|BallBalance]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter|BallBalance|Ingenuity]
 
 One "step" = one pre_physics_step (reset-id compaction, reset of the flagged envs, action scaling /
 PD torques) + one post_physics_step (progress, obs, reward, done[, in-step reset]) over a batch of
@@ -414,6 +414,54 @@ class BallBalanceBench:
         return step
 
 
+class IngenuityBench:
+    """Ingenuity obs(13) + reward + done, reset + set_targets compactions, thrust vectors."""
+
+    def __init__(self, name, n, dev, seed):
+        from helpers import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+
+        self.env, self.task = make_task("Ingenuity", n, device=dev, seed=seed)
+        t = self.task
+        st = workloads.ingenuity_state(n, t._env_pos, device=dev, seed=seed)
+        workloads.load_ingenuity_state(t, st)
+        for v in (t._copters, t._balls):
+            v.apply_resets = False
+        self.actions = st["actions"]
+        self.post_bytes = 84 + 72  # R root pos 12 + rot 16 + vel 24 + target 12 + env_pos 12 + progress 8; W obs 52 + rew 4 + reset 8 + progress 8
+        self.kernel = "ingenuity_post_kernel"
+        self.workload = f"Ingenuity obs(13)+reward+reset fused, {n} envs per GPU, synthetic root state"
+        self.extra_cfg = {"num_dof": 4}
+
+    def pre(self):
+        self.task.pre_physics_step(self.actions)
+
+    def post(self):
+        self.task.post_physics_step()
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from oracle import ingenuity_oracle as io
+
+        spec = io.IngenuitySpec()
+        env_pos = torch.zeros(n, 3)
+        st = workloads.ingenuity_state(n, env_pos, device="cpu", seed=1234)
+        b = io.IngenuityBuffers(torch.zeros(n, 13), torch.zeros(n), st["reset"].clone(), st["progress"].clone(), st["targets"].clone(),
+                                torch.zeros(n, 2, 3), st["dof_pos"].clone(), st["dof_vel"].clone())
+        init_pos, init_rot = st["root_pos"].clone(), st["root_rot"].clone()
+
+        def step():
+            io.pre_physics(spec, b, st["actions"], env_pos, init_pos, init_rot, init_rot,
+                           lambda ids: torch.rand(len(ids), 5), lambda ids: (torch.rand(len(ids), 2), torch.rand(len(ids))))
+            io.post_physics(spec, b, st["root_pos"], st["root_rot"], st["root_vel"], env_pos)
+
+        return step
+
+
 class AnymalFlatBench:
     """Anymal on flat ground (obs 48, 6-term reward, non-sticky done, position targets)."""
 
@@ -462,9 +510,9 @@ class AnymalFlatBench:
         return step
 
 
-ADAPTERS = {"BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
-DEFAULT_ENVS = {"BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
-CPU_ENVS = {"BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
+ADAPTERS = {"Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
+DEFAULT_ENVS = {"Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
+CPU_ENVS = {"Ingenuity": 1 << 18, "BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
 def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:

@@ -700,6 +700,80 @@ int oige_ball_balance_reset_idx(const oige_ball_balance_params* params, const oi
                                 const oige_ball_balance_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
                                 oige_stream_t stream);
 
+/* ------------------------------------------------------------------ Ingenuity
+ * tasks/ingenuity.py.  Scalars: cfg/task/Ingenuity.yaml:5-13, ingenuity.py:56-57.                                */
+#define OIGE_INGENUITY_OBS 13
+
+typedef struct oige_ingenuity_params {
+  float dt;
+  float thrust_limit;             /* 2000 */
+  float thrust_lateral_component; /* 0.2 */
+  float clip_actions;             /* with OIGE_PRE_CLAMP_ACTIONS */
+  int32_t max_episode_length;     /* 2000 */
+  int32_t reserved0[3];
+} oige_ingenuity_params;
+
+typedef struct oige_ingenuity_state {  /* view getters of get_observations (:129-130), world frame, read-only */
+  const float* root_pos;        /* (N,3) */
+  const float* root_rot;        /* (N,4) */
+  const float* root_velocities; /* (N,6) */
+  const float* env_pos;         /* (N,3) */
+} oige_ingenuity_state;
+
+typedef struct oige_ingenuity_buffers {
+  float* obs_buf;            /* (N,13) */
+  float* rew_buf;            /* (N,) */
+  int64_t* reset_buf;        /* (N,) */
+  int64_t* progress_buf;     /* (N,) */
+  float* target_positions;   /* (N,3) rewritten by set_targets */
+  float* thrusts;            /* (N,2,3) */
+  float* dof_pos;            /* (N,4) the task's own copy (:201); columns 1, 3 re-drawn on reset */
+  float* dof_vel;            /* (N,4) the task's own copy; zeroed on reset, columns 1 / 3 = +-50 every step (:178-179) */
+  int32_t* reset_workspace;  /* oige_workspace_ints(N): reset ids */
+  int32_t* target_workspace; /* oige_workspace_ints(N): set_targets ids */
+} oige_ingenuity_buffers;
+
+/* post_physics_step: progress += 1, get_observations (:128-147), calculate_metrics (:244-268), is_done (:270-281). */
+int oige_ingenuity_post_physics(const oige_ingenuity_params* params, const oige_ingenuity_state* state,
+                                const oige_ingenuity_buffers* buffers, int64_t num_envs, uint32_t stages,
+                                oige_stream_t stream);
+
+typedef struct oige_ingenuity_reset_io {
+  const float* initial_root_pos; /* (N,3) */
+  const float* initial_root_rot; /* (N,4) */
+  const float* initial_ball_rot; /* (N,4) */
+  const float* env_pos;          /* (N,3) */
+  const float* u_reset;          /* NULL, or (n,5) U[0,1): dof_pos[:,1], dof_pos[:,3], x, y, z (:228-236) */
+  const float* u_target;         /* NULL, or (m,3) U[0,1): the (m,2) draw then the (m,) draw of :217-218 */
+  uint64_t seed;
+  uint64_t step;
+  int64_t* env_ids;              /* out (N,) ascending == reset_buf.nonzero() */
+  int64_t* count;                /* out device scalar */
+  float* dof_pos_out;            /* out (n,4) */
+  float* dof_vel_out;            /* out (n,4) zeros */
+  float* root_pos_out;           /* out (n,3) */
+  float* root_rot_out;           /* out (n,4) */
+  float* root_vel_out;           /* out (n,6) zeros */
+  int64_t* target_ids;           /* out (N,) ascending == (progress_buf % 500 == 0).nonzero() after the resets */
+  int64_t* target_count;         /* out device scalar */
+  float* ball_pos_out;           /* out (m,3) target + env_pos, z + 0.4 */
+  float* ball_rot_out;           /* out (m,4) */
+} oige_ingenuity_reset_io;
+
+/* pre_physics_step (:149-190): both compactions, reset_idx, set_targets, thrust vectors, rotor speeds.             */
+int oige_ingenuity_pre_physics(const oige_ingenuity_params* params, const float* actions_in,
+                               const oige_ingenuity_buffers* buffers, const oige_ingenuity_reset_io* reset_io,
+                               int64_t num_envs, uint32_t flags, oige_stream_t stream);
+
+/* reset_idx(env_ids) (:225-249) / set_targets(env_ids) (:213-223) with caller-provided ids (device counts in
+ * reset_io->count / ->target_count).                                                                              */
+int oige_ingenuity_reset_idx(const oige_ingenuity_params* params, const oige_ingenuity_buffers* buffers,
+                             const oige_ingenuity_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                             oige_stream_t stream);
+int oige_ingenuity_set_targets(const oige_ingenuity_params* params, const oige_ingenuity_buffers* buffers,
+                               const oige_ingenuity_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                               oige_stream_t stream);
+
 /* ------------------------------------------------------------------ Cartpole
  * tasks/cartpole.py:91-164.                                                                 */
 typedef struct oige_cartpole_params {

@@ -220,6 +220,27 @@ class BallBalanceResetIO(C.Structure):
                            "bot_vel_out", "dof_pos_out")]
 
 
+class IngenuityParams(C.Structure):
+    _fields_ = [("dt", _f), ("thrust_limit", _f), ("thrust_lateral_component", _f), ("clip_actions", _f),
+                ("max_episode_length", C.c_int32), ("reserved0", C.c_int32 * 3)]
+
+
+class IngenuityState(C.Structure):
+    _fields_ = [(n, _fp) for n in ("root_pos", "root_rot", "root_velocities", "env_pos")]
+
+
+class IngenuityBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "target_positions", "thrusts", "dof_pos",
+                                   "dof_vel", "reset_workspace", "target_workspace")]
+
+
+class IngenuityResetIO(C.Structure):
+    _fields_ = [(n, _fp) for n in ("initial_root_pos", "initial_root_rot", "initial_ball_rot", "env_pos", "u_reset", "u_target")] + [
+        ("seed", C.c_uint64), ("step", C.c_uint64)] + [
+        (n, _fp) for n in ("env_ids", "count", "dof_pos_out", "dof_vel_out", "root_pos_out", "root_rot_out", "root_vel_out",
+                           "target_ids", "target_count", "ball_pos_out", "ball_rot_out")]
+
+
 NOISE_ADDITIVE, NOISE_SCALING = 0, 1
 NOISE_GAUSSIAN, NOISE_UNIFORM, NOISE_LOGUNIFORM = 0, 1, 2
 
@@ -288,6 +309,14 @@ SIGNATURES = {
                                                 C.POINTER(BallBalanceResetIO), C.c_int64, C.c_uint32, _P]),
     "oige_ball_balance_reset_idx": (C.c_int, [C.POINTER(BallBalanceParams), C.POINTER(BallBalanceBuffers),
                                               C.POINTER(BallBalanceResetIO), C.c_int64, C.c_int64, _P]),
+    "oige_ingenuity_post_physics": (C.c_int, [C.POINTER(IngenuityParams), C.POINTER(IngenuityState), C.POINTER(IngenuityBuffers),
+                                              C.c_int64, C.c_uint32, _P]),
+    "oige_ingenuity_pre_physics": (C.c_int, [C.POINTER(IngenuityParams), _P, C.POINTER(IngenuityBuffers),
+                                             C.POINTER(IngenuityResetIO), C.c_int64, C.c_uint32, _P]),
+    "oige_ingenuity_reset_idx": (C.c_int, [C.POINTER(IngenuityParams), C.POINTER(IngenuityBuffers), C.POINTER(IngenuityResetIO),
+                                           C.c_int64, C.c_int64, _P]),
+    "oige_ingenuity_set_targets": (C.c_int, [C.POINTER(IngenuityParams), C.POINTER(IngenuityBuffers), C.POINTER(IngenuityResetIO),
+                                             C.c_int64, C.c_int64, _P]),
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "oige_dr_noise_count": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_dr_noise_apply": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),

@@ -281,3 +281,33 @@ def load_ball_balance_state(task, st: Dict[str, Tensor]) -> None:
     task.dof_position_targets.copy_(st["targets"].to(dev))
     task.progress_buf.copy_(st["progress"].to(dev))
     task.reset_buf.copy_(st["reset"].to(dev))
+
+
+def ingenuity_state(n: int, env_pos: Tensor, device="cpu", seed: int = 1234) -> Dict[str, Tensor]:
+    """Ingenuity: targets in [-1,1]^2 x [1,2], root within ~1.5 m of its target (a few per cent below the
+    0.5 m reset height), progress up to the 2000-step episode (0.2 % of the envs at a multiple of 500: new targets)."""
+    g = _gen(device, seed)
+    f = dict(device=device, dtype=torch.float32, generator=g)
+    env_pos = env_pos.to(device)
+    tp = torch.cat([torch.rand(n, 2, **f) * 2 - 1, torch.rand(n, 1, **f) + 1], -1).contiguous()
+    q = torch.randn(n, 4, **f) * 0.3
+    q[:, 0] += 1.0
+    q = (q / q.norm(dim=-1, keepdim=True)).contiguous()
+    return dict(
+        root_pos=(env_pos + tp + torch.randn(n, 3, **f) * 0.7).contiguous(), root_rot=q, root_vel=torch.randn(n, 6, **f),
+        targets=tp, actions=torch.rand(n, 6, **f) * 2.0 - 1.0, dof_pos=torch.rand(n, 4, **f) - 0.5, dof_vel=torch.randn(n, 4, **f),
+        progress=torch.randint(0, 2000, (n,), device=device, generator=g, dtype=torch.int64),
+        reset=(torch.rand(n, **f) < 0.05).long(),
+    )
+
+
+def load_ingenuity_state(task, st: Dict[str, Tensor]) -> None:
+    dev, v = task.device, task._copters
+    v.positions.copy_(st["root_pos"].to(dev))
+    v.orientations.copy_(st["root_rot"].to(dev))
+    v.velocities.copy_(st["root_vel"].to(dev))
+    task.target_positions.copy_(st["targets"].to(dev))
+    task.dof_pos.copy_(st["dof_pos"].to(dev))
+    task.dof_vel.copy_(st["dof_vel"].to(dev))
+    task.progress_buf.copy_(st["progress"].to(dev))
+    task.reset_buf.copy_(st["reset"].to(dev))

@@ -1,0 +1,266 @@
+"""IngenuityTask -- host-side mirror of /root/reference/omniisaacgymenvs/tasks/ingenuity.py:44-281, whose arithmetic runs
+in liboige_hip.so (csrc/ingenuity.hip).  Same constructor, attributes and methods: ``get_observations /
+calculate_metrics / is_done / pre_physics_step / set_targets / reset_idx / post_reset`` plus the fused
+``post_physics_step``.  No torch/CPU fallback.
+
+``reset_idx`` / ``set_targets`` draw with torch in the reference's order (:228-236, :217-218); the sync-free
+``pre_physics_step`` uses in-kernel Philox keyed by (seed, step, env id) and runs both compactions on the device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .. import _lib
+from ..sim.synthetic import SyntheticArticulationView, SyntheticRigidPrimView
+from .base.rl_task import RLTask
+
+
+class SyntheticIngenuityView(SyntheticArticulationView):
+    """IngenuityView surface used by the task: 4 DOFs, ``physics_rotors[0..1].apply_forces`` (views/ingenuity_view.py)."""
+
+    def __init__(self, name: str, count: int, device) -> None:
+        super().__init__(name=name, count=count, num_dof=4, device=device)
+        self.physics_rotors = []
+        for i in range(2):
+            r = SyntheticRigidPrimView(f"physics_rotor_{i}_view", count, device)
+            r.applied_forces = None
+            r.apply_forces = (lambda rr: (lambda forces, indices=None: setattr(rr, "applied_forces", forces)))(r)
+            self.physics_rotors.append(r)
+
+
+class IngenuityTask(RLTask):
+    def __init__(self, name, sim_config, env, offset=None) -> None:
+        self.update_config(sim_config)
+        self.thrust_limit = 2000
+        self.thrust_lateral_component = 0.2
+        self._num_observations = 13
+        self._num_actions = 6
+        self._ingenuity_position = torch.tensor([0, 0, 1.0])
+        self._ball_position = torch.tensor([0, 0, 1.0])
+        self.fused = True
+        self.sync_free = True
+        self.supports_action_clamp = True
+        self._step_count = 0
+        RLTask.__init__(self, name=name, env=env)
+
+    def update_config(self, sim_config):
+        self._sim_config = sim_config
+        self._cfg = sim_config.config
+        self._task_cfg = sim_config.task_config
+        self._num_envs = self._task_cfg["env"]["numEnvs"]
+        self._env_spacing = self._task_cfg["env"]["envSpacing"]
+        self._max_episode_length = self._task_cfg["env"]["maxEpisodeLength"]
+        self.dt = self._task_cfg["sim"]["dt"]
+
+    def set_up_scene(self, scene=None) -> None:
+        RLTask.set_up_scene(self, scene)
+        self._copters = SyntheticIngenuityView("ingenuity_view", self._num_envs, self.device)
+        self._copters.positions[:] = self._env_pos + self._ingenuity_position.to(self.device)
+        self._balls = SyntheticRigidPrimView("targets_view", self._num_envs, self.device)
+        self._balls.positions[:] = self._env_pos + self._ball_position.to(self.device)
+
+    def initialize_views(self, scene=None):
+        self.set_up_scene(scene)
+
+    def post_reset(self):
+        n, dev = self._num_envs, self._device
+        f = dict(dtype=torch.float32, device=dev)
+        self.spinning_indices = torch.tensor([1, 3], device=dev)
+        self.all_indices = torch.arange(n, dtype=torch.int32, device=dev)
+        self.target_positions = torch.zeros((n, 3), **f)
+        self.target_positions[:, 2] = 1
+        self.root_pos, self.root_rot = self._copters.get_world_poses()
+        self.root_velocities = self._copters.get_velocities()
+        self.dof_pos = self._copters.get_joint_positions()
+        self.dof_vel = self._copters.get_joint_velocities()
+        self.initial_ball_pos, self.initial_ball_rot = self._balls.get_world_poses()
+        self.initial_root_pos, self.initial_root_rot = self.root_pos.clone(), self.root_rot.clone()
+        self.thrusts = torch.zeros((n, 2, 3), **f)
+
+        # device-side scratch of the HIP path
+        self._reset_workspace = _lib.new_workspace(n, dev)
+        self._target_workspace = _lib.new_workspace(n, dev)
+        i64 = dict(dtype=torch.int64, device=dev)
+        self._reset_out = {
+            "env_ids": torch.zeros(n, **i64), "count": torch.zeros(1, **i64),
+            "dof_pos": torch.zeros((n, 4), **f), "dof_vel": torch.zeros((n, 4), **f),
+            "root_pos": torch.zeros((n, 3), **f), "root_rot": torch.zeros((n, 4), **f), "root_vel": torch.zeros((n, 6), **f),
+            "target_ids": torch.zeros(n, **i64), "target_count": torch.zeros(1, **i64),
+            "ball_pos": torch.zeros((n, 3), **f), "ball_rot": torch.zeros((n, 4), **f),
+        }
+
+    # ------------------------------------------------------------------ C-ABI argument blocks
+    def _params(self) -> _lib.IngenuityParams:
+        p = _lib.IngenuityParams()
+        p.dt, p.thrust_limit, p.thrust_lateral_component = self.dt, self.thrust_limit, self.thrust_lateral_component
+        p.clip_actions = float(min(self.clip_actions, 3.0e38))
+        p.max_episode_length = int(self._max_episode_length)
+        return p
+
+    def _buffers(self) -> _lib.IngenuityBuffers:
+        n, rq = self._num_envs, _lib.require_device_tensor
+        rq(self.obs_buf, torch.float32, (n, 13), "obs_buf")
+        rq(self.rew_buf, torch.float32, (n,), "rew_buf")
+        rq(self.reset_buf, torch.int64, (n,), "reset_buf")
+        rq(self.progress_buf, torch.int64, (n,), "progress_buf")
+        rq(self.target_positions, torch.float32, (n, 3), "target_positions")
+        rq(self.thrusts, torch.float32, (n, 2, 3), "thrusts")
+        rq(self.dof_pos, torch.float32, (n, 4), "dof_pos")
+        rq(self.dof_vel, torch.float32, (n, 4), "dof_vel")
+        b = _lib.IngenuityBuffers()
+        b.obs_buf, b.rew_buf = self.obs_buf.data_ptr(), self.rew_buf.data_ptr()
+        b.reset_buf, b.progress_buf = self.reset_buf.data_ptr(), self.progress_buf.data_ptr()
+        b.target_positions, b.thrusts = self.target_positions.data_ptr(), self.thrusts.data_ptr()
+        b.dof_pos, b.dof_vel = self.dof_pos.data_ptr(), self.dof_vel.data_ptr()
+        b.reset_workspace, b.target_workspace = self._reset_workspace.data_ptr(), self._target_workspace.data_ptr()
+        return b
+
+    def _state(self) -> _lib.IngenuityState:
+        n, rq = self._num_envs, _lib.require_device_tensor
+        self.root_pos, self.root_rot = self._copters.get_world_poses(clone=False)
+        self.root_velocities = self._copters.get_velocities(clone=False)
+        rq(self.root_pos, torch.float32, (n, 3), "root_pos")
+        rq(self.root_rot, torch.float32, (n, 4), "root_rot")
+        rq(self.root_velocities, torch.float32, (n, 6), "root_velocities")
+        s = _lib.IngenuityState()
+        s.root_pos, s.root_rot = self.root_pos.data_ptr(), self.root_rot.data_ptr()
+        s.root_velocities, s.env_pos = self.root_velocities.data_ptr(), self._env_pos.data_ptr()
+        return s
+
+    def _post(self, stages: int) -> None:
+        p, s, b = self._params(), self._state(), self._buffers()
+        rc = _lib.load().oige_ingenuity_post_physics(C.byref(p), C.byref(s), C.byref(b), self._num_envs, stages,
+                                                     _lib.current_stream(self.obs_buf.device))
+        _lib.check(rc, "oige_ingenuity_post_physics")
+
+    # ------------------------------------------------------------------ RLTask methods
+    def get_observations(self) -> dict:
+        self._post(_lib.STAGE_OBS)
+        return {self._copters.name: {"obs_buf": self.obs_buf}}
+
+    def calculate_metrics(self) -> None:
+        self._post(_lib.STAGE_METRICS)
+
+    def is_done(self) -> None:
+        self._post(_lib.STAGE_DONE)
+
+    def post_physics_step(self):
+        if not self.fused:
+            return RLTask.post_physics_step(self)
+        self._post(_lib.STAGE_ALL if self._env.world.is_playing() else _lib.STAGE_PROGRESS)
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def _reset_io(self, u_reset=None, u_target=None) -> _lib.IngenuityResetIO:
+        r = _lib.IngenuityResetIO()
+        r.initial_root_pos, r.initial_root_rot = self.initial_root_pos.data_ptr(), self.initial_root_rot.data_ptr()
+        r.initial_ball_rot, r.env_pos = self.initial_ball_rot.data_ptr(), self._env_pos.data_ptr()
+        if u_reset is not None:
+            r.u_reset = u_reset.data_ptr()
+        if u_target is not None:
+            r.u_target = u_target.data_ptr()
+        r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
+        r.step = self._step_count
+        o = self._reset_out
+        r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
+        r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
+        r.root_pos_out, r.root_rot_out, r.root_vel_out = o["root_pos"].data_ptr(), o["root_rot"].data_ptr(), o["root_vel"].data_ptr()
+        r.target_ids, r.target_count = o["target_ids"].data_ptr(), o["target_count"].data_ptr()
+        r.ball_pos_out, r.ball_rot_out = o["ball_pos"].data_ptr(), o["ball_rot"].data_ptr()
+        return r
+
+    def _apply_reset_writes(self, n=None) -> None:
+        o = self._reset_out
+        if n is None:
+            kw, sl = dict(indices=o["env_ids"], count=o["count"]), slice(None)
+        else:
+            kw, sl = dict(indices=o["env_ids"][:n].to(torch.int32)), slice(0, n)
+        self._copters.set_joint_positions(o["dof_pos"][sl], **kw)
+        self._copters.set_joint_velocities(o["dof_vel"][sl], **kw)
+        self._copters.set_world_poses(o["root_pos"][sl], o["root_rot"][sl], **kw)
+        self._copters.set_velocities(o["root_vel"][sl], **kw)
+
+    def _apply_target_writes(self, n=None) -> None:
+        o = self._reset_out
+        if n is None:
+            self._balls.set_world_poses(o["ball_pos"], o["ball_rot"], indices=o["target_ids"], count=o["target_count"])
+        else:
+            self._balls.set_world_poses(o["ball_pos"][:n], o["ball_rot"][:n], indices=o["target_ids"][:n])
+
+    def pre_physics_step(self, actions) -> None:
+        if not self.world.is_playing():
+            return
+        n = self._num_envs
+        actions = actions.to(self._device)
+        _lib.require_device_tensor(actions, torch.float32, (n, 6), "actions")
+        self._step_count += 1
+        flags, ids = 0, None
+        if not self.sync_free:
+            # the reference's flow: host-visible id lists, torch-drawn noise (:153-160)
+            o = self._reset_out
+            _lib.compact(self.reset_buf, self._reset_workspace, o["env_ids"], o["count"])
+            num = int(o["count"].item())
+            if num > 0:
+                ids = o["env_ids"][:num].clone()
+                self.reset_idx(ids)
+            set_target_ids = (self.progress_buf % 500 == 0).nonzero(as_tuple=False).squeeze(-1)
+            if len(set_target_ids) > 0:
+                self.set_targets(set_target_ids)
+            self.progress_buf_saved = None
+        if self.clamp_actions_in_kernel:
+            flags |= _lib.PRE_CLAMP_ACTIONS
+        if not self.sync_free:
+            # nothing is flagged any more: keep the kernel from re-drawing targets for the envs at progress % 500 == 0
+            keep = self.progress_buf.clone()
+            self.progress_buf[self.progress_buf % 500 == 0] += 1
+        p, b, r = self._params(), self._buffers(), self._reset_io()
+        rc = _lib.load().oige_ingenuity_pre_physics(C.byref(p), actions.data_ptr(), C.byref(b), C.byref(r), n, flags,
+                                                    _lib.current_stream(self.obs_buf.device))
+        _lib.check(rc, "oige_ingenuity_pre_physics")
+        if self.sync_free:
+            self._apply_reset_writes(None)
+            self._apply_target_writes(None)
+        else:
+            self.progress_buf.copy_(keep)
+            if ids is not None:
+                self.thrusts[ids] = 0          # :175
+                self.dof_vel[ids, 0] = 0       # reset_idx zeroed the rows before the spin columns were set (:230)
+                self.dof_vel[ids, 2] = 0
+        self._copters.set_joint_velocities(self.dof_vel)
+        for i in range(2):
+            self._copters.physics_rotors[i].apply_forces(self.thrusts[:, i], indices=self.all_indices)
+
+    def set_targets(self, env_ids):
+        num_sets = len(env_ids)
+        if num_sets == 0:
+            return
+        dev = self._device
+        env_ids = env_ids.to(device=dev, dtype=torch.int64).contiguous()
+        u_xy = torch.rand((num_sets, 2), device=dev)  # :217
+        u_z = torch.rand(num_sets, device=dev)        # :218
+        u = torch.cat([u_xy, u_z.unsqueeze(-1)], dim=-1).contiguous()
+        o = self._reset_out
+        o["target_ids"][:num_sets] = env_ids
+        o["target_count"].fill_(num_sets)
+        p, b, r = self._params(), self._buffers(), self._reset_io(u_target=u)
+        rc = _lib.load().oige_ingenuity_set_targets(C.byref(p), C.byref(b), C.byref(r), self._num_envs, num_sets,
+                                                    _lib.current_stream(self.obs_buf.device))
+        _lib.check(rc, "oige_ingenuity_set_targets")
+        self._apply_target_writes(num_sets)
+
+    def reset_idx(self, env_ids):
+        num_resets = len(env_ids)
+        if num_resets == 0:
+            return
+        dev = self._device
+        env_ids = env_ids.to(device=dev, dtype=torch.int64).contiguous()
+        u = torch.cat([torch.rand(num_resets, 1, device=dev) for _ in range(5)], dim=-1).contiguous()  # :228-236 order
+        o = self._reset_out
+        o["env_ids"][:num_resets] = env_ids
+        o["count"].fill_(num_resets)
+        p, b, r = self._params(), self._buffers(), self._reset_io(u_reset=u)
+        rc = _lib.load().oige_ingenuity_reset_idx(C.byref(p), C.byref(b), C.byref(r), self._num_envs, num_resets,
+                                                  _lib.current_stream(self.obs_buf.device))
+        _lib.check(rc, "oige_ingenuity_reset_idx")
+        self._apply_reset_writes(num_resets)

@@ -134,6 +134,14 @@ TASK_DEFAULTS["BallBalance"] = {
     "sim": dict(_SIM, dt=0.01),
 }
 
+# cfg/task/Ingenuity.yaml:5-13
+TASK_DEFAULTS["Ingenuity"] = {
+    "name": "Ingenuity",
+    "env": {"numEnvs": 4096, "envSpacing": 2.5, "maxEpisodeLength": 2000, "enableDebugVis": False,
+            "clipObservations": 5.0, "clipActions": 1.0},
+    "sim": dict(_SIM, dt=0.01, gravity=[0.0, 0.0, -3.721]),
+}
+
 # cfg/task/AnymalTerrain.yaml:5-103
 TASK_DEFAULTS["AnymalTerrain"] = {
     "name": "AnymalTerrain",
