@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- fused obs+reward+reset env-steps/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter|BallBalance|Ingenuity]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter|BallBalance|Ingenuity|Crazyflie]
 
 One "step" = one pre_physics_step (reset-id compaction, reset of the flagged envs, action scaling /
 PD torques) + one post_physics_step (progress, obs, reward, done[, in-step reset]) over a batch of
@@ -462,6 +462,54 @@ class IngenuityBench:
         return step
 
 
+class CrazyflieBench:
+    """Crazyflie obs(18) + 4-term reward + 8 episode sums + done; motor filter, two compactions, extras."""
+
+    def __init__(self, name, n, dev, seed):
+        from helpers import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+
+        self.env, self.task = make_task("Crazyflie", n, device=dev, seed=seed)
+        t = self.task
+        st = workloads.crazyflie_state(n, t._env_pos, device=dev, seed=seed)
+        workloads.load_crazyflie_state(t, st)
+        for v in (t._copters, t._balls):
+            v.apply_resets = False
+        self.actions = st["actions"]
+        self.post_bytes = 132 + 124  # csrc/crazyflie.hip header
+        self.kernel = "crazyflie_post_kernel"
+        self.workload = f"Crazyflie obs(18)+reward+episode sums+reset fused, {n} envs per GPU, synthetic root state"
+        self.extra_cfg = {"num_dof": 4}
+
+    def pre(self):
+        self.task.pre_physics_step(self.actions)
+
+    def post(self):
+        self.task.post_physics_step()
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from oracle import crazyflie_oracle as co
+
+        spec = co.CrazyflieSpec()
+        env_pos = torch.zeros(n, 3)
+        st = workloads.crazyflie_state(n, env_pos, device="cpu", seed=1234)
+        b = co.CrazyflieBuffers(torch.zeros(n, 18), torch.zeros(n), st["reset"].clone(), st["progress"].clone(), st["targets"].clone(),
+                                st["prev_actions"].clone(), torch.zeros(n, 4, 3), st["cmds_damp"].clone(), st["rot_damp"].clone(),
+                                torch.zeros(n, 4), torch.zeros(n, 4), {k: st["episode_sums"][i].clone() for i, k in enumerate(co.EPISODE_KEYS)})
+        init_pos, init_rot = st["root_pos"].clone(), st["root_rot"].clone()
+
+        def step():
+            co.pre_physics(spec, b, st["actions"], st["root_rot"], env_pos, init_pos, init_rot, init_rot, 0.01 * torch.randn(4))
+            co.post_physics(spec, b, st["root_pos"], st["root_rot"], st["root_vel"], env_pos)
+
+        return step
+
+
 class AnymalFlatBench:
     """Anymal on flat ground (obs 48, 6-term reward, non-sticky done, position targets)."""
 
@@ -510,9 +558,9 @@ class AnymalFlatBench:
         return step
 
 
-ADAPTERS = {"Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
-DEFAULT_ENVS = {"Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
-CPU_ENVS = {"Ingenuity": 1 << 18, "BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
+ADAPTERS = {"Crazyflie": CrazyflieBench, "Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
+DEFAULT_ENVS = {"Crazyflie": 1 << 20, "Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
+CPU_ENVS = {"Crazyflie": 1 << 18, "Ingenuity": 1 << 18, "BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
 def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:

@@ -774,6 +774,86 @@ int oige_ingenuity_set_targets(const oige_ingenuity_params* params, const oige_i
                                const oige_ingenuity_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
                                oige_stream_t stream);
 
+/* ------------------------------------------------------------------ Crazyflie
+ * tasks/crazyflie.py.  Scalars: cfg/task/Crazyflie.yaml:5-13, crazyflie.py:57-90,262-268.                        */
+#define OIGE_CRAZYFLIE_OBS 18
+#define OIGE_CRAZYFLIE_EPISODE_SUMS 8  /* rew_pos, rew_orient, rew_effort, rew_spin, raw_dist, raw_orient, raw_effort, raw_spin */
+
+typedef struct oige_crazyflie_params {
+  float motor_tau_up;         /* (float)(4 dt / (motor_damp_time_up + 1e-6)) (:77) */
+  float motor_tau_down;       /* (:78) */
+  float prop_max_rot;         /* 433.3 (:268) */
+  float clip_actions;         /* with OIGE_PRE_CLAMP_ACTIONS */
+  float thrust_max[4];        /* grav_z * mass * thrust_to_weight * motor_assymetry / 4 (:262) */
+  int32_t max_episode_length; /* 700 */
+  int32_t reserved0[3];
+} oige_crazyflie_params;
+
+typedef struct oige_crazyflie_state {  /* view getters of get_observations (:141-142), world frame, read-only */
+  const float* root_pos;        /* (N,3) */
+  const float* root_rot;        /* (N,4) */
+  const float* root_velocities; /* (N,6) */
+  const float* env_pos;         /* (N,3) */
+} oige_crazyflie_state;
+
+typedef struct oige_crazyflie_buffers {
+  float* obs_buf;            /* (N,18) */
+  float* rew_buf;            /* (N,) */
+  int64_t* reset_buf;        /* (N,) */
+  int64_t* progress_buf;     /* (N,) */
+  float* target_positions;   /* (N,3) */
+  float* actions;            /* (N,4) the task's self.actions (:180), read by the effort reward */
+  float* thrusts;            /* (N,4,3) */
+  float* thrust_cmds_damp;   /* (N,4) */
+  float* thrust_rot_damp;    /* (N,4) */
+  float* dof_pos;            /* (N,4) the task's own copy */
+  float* dof_vel;            /* (N,4) the task's own copy: rotor speeds (:247-251) */
+  float* episode_sums;       /* (8,N): the eight episode_sums tensors as rows of one block */
+  float* extras;             /* (8,) extras["episode"][key], written when at least one env resets */
+  int32_t* reset_workspace;  /* oige_workspace_ints(N) */
+  int32_t* target_workspace; /* oige_workspace_ints(N) */
+  float* reduce_workspace;   /* 8 * ceil(N / 256) floats */
+} oige_crazyflie_buffers;
+
+/* post_physics_step: progress += 1, get_observations (:140-164), calculate_metrics (:337-378), is_done (:380-395). */
+int oige_crazyflie_post_physics(const oige_crazyflie_params* params, const oige_crazyflie_state* state,
+                                const oige_crazyflie_buffers* buffers, int64_t num_envs, uint32_t stages,
+                                oige_stream_t stream);
+
+typedef struct oige_crazyflie_reset_io {
+  const float* initial_root_pos; /* (N,3) */
+  const float* initial_root_rot; /* (N,4) */
+  const float* initial_ball_rot; /* (N,4) */
+  const float* env_pos;          /* (N,3) */
+  const float* thrust_noise4;    /* (4,) the step's 0.01 * torch.randn(4) (:197), drawn by the caller */
+  int64_t* env_ids;              /* out (N,) ascending == reset_buf.nonzero() */
+  int64_t* count;                /* out device scalar */
+  float* dof_pos_out;            /* out (n,4) zeros */
+  float* dof_vel_out;            /* out (n,4) zeros */
+  float* root_pos_out;           /* out (n,3) */
+  float* root_rot_out;           /* out (n,4) */
+  float* root_vel_out;           /* out (n,6) zeros */
+  int64_t* target_ids;           /* out (N,) ascending == (progress_buf % 500 == 0).nonzero() after the resets */
+  int64_t* target_count;         /* out device scalar */
+  float* ball_pos_out;           /* out (m,3) */
+  float* ball_rot_out;           /* out (m,4) */
+} oige_crazyflie_reset_io;
+
+/* pre_physics_step (:166-258): both compactions, reset_idx incl. the episode-sum means (extras), set_targets, motor
+ * filter, thrust along the body z axis (root_rot: the view's current orientations), rotor speeds.                 */
+int oige_crazyflie_pre_physics(const oige_crazyflie_params* params, const float* actions_in, const float* root_rot,
+                               const oige_crazyflie_buffers* buffers, const oige_crazyflie_reset_io* reset_io,
+                               int64_t num_envs, uint32_t flags, oige_stream_t stream);
+
+/* reset_idx(env_ids) rows, flags and filter states (:313-329; the episode-sum means of :331-335 stay two torch lines
+ * with the caller in this flow) / set_targets(env_ids) (:300-311), caller-provided ids.                           */
+int oige_crazyflie_reset_idx(const oige_crazyflie_params* params, const oige_crazyflie_buffers* buffers,
+                             const oige_crazyflie_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                             oige_stream_t stream);
+int oige_crazyflie_set_targets(const oige_crazyflie_params* params, const oige_crazyflie_buffers* buffers,
+                               const oige_crazyflie_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                               oige_stream_t stream);
+
 /* ------------------------------------------------------------------ Cartpole
  * tasks/cartpole.py:91-164.                                                                 */
 typedef struct oige_cartpole_params {

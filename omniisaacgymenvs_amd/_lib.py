@@ -241,6 +241,27 @@ class IngenuityResetIO(C.Structure):
                            "target_ids", "target_count", "ball_pos_out", "ball_rot_out")]
 
 
+class CrazyflieParams(C.Structure):
+    _fields_ = [("motor_tau_up", _f), ("motor_tau_down", _f), ("prop_max_rot", _f), ("clip_actions", _f), ("thrust_max", _f * 4),
+                ("max_episode_length", C.c_int32), ("reserved0", C.c_int32 * 3)]
+
+
+class CrazyflieState(C.Structure):
+    _fields_ = [(n, _fp) for n in ("root_pos", "root_rot", "root_velocities", "env_pos")]
+
+
+class CrazyflieBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "target_positions", "actions", "thrusts",
+                                   "thrust_cmds_damp", "thrust_rot_damp", "dof_pos", "dof_vel", "episode_sums", "extras",
+                                   "reset_workspace", "target_workspace", "reduce_workspace")]
+
+
+class CrazyflieResetIO(C.Structure):
+    _fields_ = [(n, _fp) for n in ("initial_root_pos", "initial_root_rot", "initial_ball_rot", "env_pos", "thrust_noise4", "env_ids",
+                                   "count", "dof_pos_out", "dof_vel_out", "root_pos_out", "root_rot_out", "root_vel_out",
+                                   "target_ids", "target_count", "ball_pos_out", "ball_rot_out")]
+
+
 NOISE_ADDITIVE, NOISE_SCALING = 0, 1
 NOISE_GAUSSIAN, NOISE_UNIFORM, NOISE_LOGUNIFORM = 0, 1, 2
 
@@ -316,6 +337,14 @@ SIGNATURES = {
     "oige_ingenuity_reset_idx": (C.c_int, [C.POINTER(IngenuityParams), C.POINTER(IngenuityBuffers), C.POINTER(IngenuityResetIO),
                                            C.c_int64, C.c_int64, _P]),
     "oige_ingenuity_set_targets": (C.c_int, [C.POINTER(IngenuityParams), C.POINTER(IngenuityBuffers), C.POINTER(IngenuityResetIO),
+                                             C.c_int64, C.c_int64, _P]),
+    "oige_crazyflie_post_physics": (C.c_int, [C.POINTER(CrazyflieParams), C.POINTER(CrazyflieState), C.POINTER(CrazyflieBuffers),
+                                              C.c_int64, C.c_uint32, _P]),
+    "oige_crazyflie_pre_physics": (C.c_int, [C.POINTER(CrazyflieParams), _P, _P, C.POINTER(CrazyflieBuffers),
+                                             C.POINTER(CrazyflieResetIO), C.c_int64, C.c_uint32, _P]),
+    "oige_crazyflie_reset_idx": (C.c_int, [C.POINTER(CrazyflieParams), C.POINTER(CrazyflieBuffers), C.POINTER(CrazyflieResetIO),
+                                           C.c_int64, C.c_int64, _P]),
+    "oige_crazyflie_set_targets": (C.c_int, [C.POINTER(CrazyflieParams), C.POINTER(CrazyflieBuffers), C.POINTER(CrazyflieResetIO),
                                              C.c_int64, C.c_int64, _P]),
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "oige_dr_noise_count": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),

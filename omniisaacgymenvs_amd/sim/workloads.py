@@ -311,3 +311,37 @@ def load_ingenuity_state(task, st: Dict[str, Tensor]) -> None:
     task.dof_vel.copy_(st["dof_vel"].to(dev))
     task.progress_buf.copy_(st["progress"].to(dev))
     task.reset_buf.copy_(st["reset"].to(dev))
+
+
+def crazyflie_state(n: int, env_pos: Tensor, device="cpu", seed: int = 1234) -> Dict[str, Tensor]:
+    """Crazyflie: target (0, 0, 2), root within ~1 m of it, near-upright quaternions (a few per cent
+    upside down or out of the [0.5, 5] m band), filter states in [0, 1], progress up to the 700-step episode."""
+    g = _gen(device, seed)
+    f = dict(device=device, dtype=torch.float32, generator=g)
+    env_pos = env_pos.to(device)
+    q = torch.randn(n, 4, **f) * 0.45
+    q[:, 0] += 1.0
+    q = (q / q.norm(dim=-1, keepdim=True)).contiguous()
+    tp = torch.zeros(n, 3, device=device)
+    tp[:, 2] = 2.0
+    return dict(
+        root_pos=(env_pos + tp + torch.randn(n, 3, **f) * 0.8).contiguous(), root_rot=q, root_vel=torch.randn(n, 6, **f) * 0.7,
+        targets=tp, actions=torch.rand(n, 4, **f) * 2.0 - 1.0, prev_actions=torch.rand(n, 4, **f) * 2.0 - 1.0,
+        cmds_damp=torch.rand(n, 4, **f), rot_damp=torch.rand(n, 4, **f), episode_sums=torch.rand(8, n, **f) * 10,
+        progress=torch.randint(0, 700, (n,), device=device, generator=g, dtype=torch.int64),
+        reset=(torch.rand(n, **f) < 0.05).long(),
+    )
+
+
+def load_crazyflie_state(task, st: Dict[str, Tensor]) -> None:
+    dev, v = task.device, task._copters
+    v.positions.copy_(st["root_pos"].to(dev))
+    v.orientations.copy_(st["root_rot"].to(dev))
+    v.velocities.copy_(st["root_vel"].to(dev))
+    task.target_positions.copy_(st["targets"].to(dev))
+    task.actions.copy_(st["prev_actions"].to(dev))
+    task.thrust_cmds_damp.copy_(st["cmds_damp"].to(dev))
+    task.thrust_rot_damp.copy_(st["rot_damp"].to(dev))
+    task._episode_sums.copy_(st["episode_sums"].to(dev))
+    task.progress_buf.copy_(st["progress"].to(dev))
+    task.reset_buf.copy_(st["reset"].to(dev))

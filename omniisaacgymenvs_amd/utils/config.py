@@ -142,6 +142,14 @@ TASK_DEFAULTS["Ingenuity"] = {
     "sim": dict(_SIM, dt=0.01, gravity=[0.0, 0.0, -3.721]),
 }
 
+# cfg/task/Crazyflie.yaml:5-13
+TASK_DEFAULTS["Crazyflie"] = {
+    "name": "Crazyflie",
+    "env": {"numEnvs": 4096, "envSpacing": 2.5, "maxEpisodeLength": 700, "enableDebugVis": False,
+            "clipObservations": 5.0, "clipActions": 1.0},
+    "sim": dict(_SIM, dt=0.01, gravity=[0.0, 0.0, -9.81]),
+}
+
 # cfg/task/AnymalTerrain.yaml:5-103
 TASK_DEFAULTS["AnymalTerrain"] = {
     "name": "AnymalTerrain",
