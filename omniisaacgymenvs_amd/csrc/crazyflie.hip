@@ -18,7 +18,7 @@
 namespace oige {
 
 constexpr int CO = OIGE_CRAZYFLIE_OBS;   // 18
-constexpr int CROW = 20;                 // LDS row: 18 obs columns padded to 5 float4
+constexpr int CROW = CO;                 // LDS rows are compact, so the tile IS the output run (stride 18: 2-way bank conflicts)
 constexpr int CE = OIGE_CRAZYFLIE_EPISODE_SUMS;  // 8
 
 struct CfPost {
@@ -93,29 +93,7 @@ __device__ __forceinline__ void cf_post_tile(const CfPost& a, float* __restrict_
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   __syncthreads();
-  if (do_obs) {
-    constexpr int NF4 = TILE * CO / 4;  // 288
-    const int valid = nv * CO;
-#pragma unroll
-    for (int it = 0; it < (NF4 + WAVE - 1) / WAVE; ++it) {
-      const int f = it * WAVE + lane;
-      if (f >= NF4) continue;
-      const int e = 4 * f;
-      float v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int ee = e + k, r = ee / CO, c = ee - r * CO;
-        v[k] = tile[r * CROW + c];
-      }
-      float* dst = a.b.obs_buf + env0 * CO + e;
-      if (FULL || e + 3 < valid) {
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        for (int k = 0; k < 4; ++k)
-          if (e + k < valid) dst[k] = v[k];
-      }
-    }
-  }
+  if (do_obs) store_tile<CO, FULL>(tile, a.b.obs_buf + env0 * CO, nv * CO);  // rows are compact: one contiguous run
 }
 
 __global__ __launch_bounds__(WAVE) void crazyflie_post_kernel(const CfPost a) {

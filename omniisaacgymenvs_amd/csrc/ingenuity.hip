@@ -15,7 +15,7 @@
 namespace oige {
 
 constexpr int IO_ = OIGE_INGENUITY_OBS;  // 13
-constexpr int IROW = 16;                 // LDS row: 13 obs columns padded to 4 float4
+constexpr int IROW = IO_;                // LDS rows are compact (odd stride: bank-conflict free), so the tile IS the output run
 
 struct IngPost {
   oige_ingenuity_params p;
@@ -80,29 +80,7 @@ __device__ __forceinline__ void ing_post_tile(const IngPost& a, float* __restric
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   __syncthreads();
-  if (do_obs) {
-    constexpr int NF4 = TILE * IO_ / 4;  // 208
-    const int valid = nv * IO_;
-#pragma unroll
-    for (int it = 0; it < (NF4 + WAVE - 1) / WAVE; ++it) {
-      const int f = it * WAVE + lane;
-      if (f >= NF4) continue;
-      const int e = 4 * f;
-      float v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int ee = e + k, r = ee / IO_, c = ee - r * IO_;
-        v[k] = tile[r * IROW + c];
-      }
-      float* dst = a.b.obs_buf + env0 * IO_ + e;
-      if (FULL || e + 3 < valid) {
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        for (int k = 0; k < 4; ++k)
-          if (e + k < valid) dst[k] = v[k];
-      }
-    }
-  }
+  if (do_obs) store_tile<IO_, FULL>(tile, a.b.obs_buf + env0 * IO_, nv * IO_);  // rows are compact: one contiguous run
 }
 
 __global__ __launch_bounds__(WAVE) void ingenuity_post_kernel(const IngPost a) {

@@ -18,7 +18,7 @@ namespace oige {
 constexpr int QD = OIGE_QUAD_DOFS;     // 8
 constexpr int QO = OIGE_QUAD_OBS;      // 21
 constexpr int QA = OIGE_QUAD_ACTIONS;  // 12
-constexpr int QROW = 24;               // LDS row: 21 obs columns, padded to 6 float4
+constexpr int QROW = QO;               // LDS rows are compact (odd stride: bank-conflict free), so the tile IS the output run
 
 struct QuadPost {
   oige_quadcopter_params p;
@@ -90,29 +90,7 @@ __device__ __forceinline__ void quad_post_tile(const QuadPost& a, float* __restr
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   __syncthreads();
-  if (do_obs) {  // the first 21 columns of every row -> obs_buf, one contiguous run of 64 x 21 floats
-    constexpr int NF4 = TILE * QO / 4;  // 336
-    const int valid = nv * QO;
-#pragma unroll
-    for (int it = 0; it < (NF4 + WAVE - 1) / WAVE; ++it) {
-      const int f = it * WAVE + lane;
-      if (f >= NF4) continue;
-      const int e = 4 * f;
-      float v[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int ee = e + k, r = ee / QO, c = ee - r * QO;
-        v[k] = tile[r * QROW + c];
-      }
-      float* dst = a.b.obs_buf + env0 * QO + e;
-      if (FULL || e + 3 < valid) {
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        for (int k = 0; k < 4; ++k)
-          if (e + k < valid) dst[k] = v[k];
-      }
-    }
-  }
+  if (do_obs) store_tile<QO, FULL>(tile, a.b.obs_buf + env0 * QO, nv * QO);  // rows are compact: one contiguous run
 }
 
 __global__ __launch_bounds__(WAVE) void quadcopter_post_kernel(const QuadPost a) {

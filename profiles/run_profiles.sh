@@ -1,9 +1,9 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): kernel-trace stats for the four task benches, then HBM byte counters for the dominant kernels.
+# Runs on the GPU box (gpurun): kernel-trace stats for the task benches, then HBM byte counters for the dominant kernels.
 # Usage: bash profiles/run_profiles.sh <tag>     outputs under gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-r01}
-TASKS=${TASKS:-"Ant Humanoid ShadowHand AnymalTerrain Anymal AllegroHand"}
+TASKS=${TASKS:-"Ant Humanoid ShadowHand AnymalTerrain Anymal AllegroHand Quadcopter BallBalance Ingenuity Crazyflie"}
 PMC=${PMC:-1}
 OUT=/tmp/prof_$TAG
 mkdir -p $OUT
