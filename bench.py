@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- fused obs+reward+reset env-steps/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter|BallBalance|Ingenuity|Crazyflie]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter|BallBalance|Ingenuity|Crazyflie|FrankaCabinet]
 
 One "step" = one pre_physics_step (reset-id compaction, reset of the flagged envs, action scaling /
 PD torques) + one post_physics_step (progress, obs, reward, done[, in-step reset]) over a batch of
@@ -510,6 +510,59 @@ class CrazyflieBench:
         return step
 
 
+class FrankaCabinetBench:
+    """FrankaCabinet grasp transforms + obs(23) + 8-term reward + sticky done; target integration, resets."""
+
+    def __init__(self, name, n, dev, seed):
+        from helpers import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+
+        self.env, self.task = make_task("FrankaCabinet", n, device=dev, seed=seed)
+        t = self.task
+        st = workloads.franka_cabinet_state(n, t._env_pos, t.franka_local_grasp_pos[0], device=dev, seed=seed)
+        workloads.load_franka_cabinet_state(t, st)
+        for v in (t._frankas, t._cabinets, t._props):
+            v.apply_resets = False
+        self.actions = st["actions"]
+        self.post_bytes = 220 + 168  # csrc/franka_cabinet.hip header
+        self.kernel = "franka_cabinet_post_kernel"
+        self.workload = f"FrankaCabinet grasp transforms+obs(23)+reward+reset fused, {n} envs per GPU, synthetic hand/drawer/DOF state"
+        self.extra_cfg = {"num_dof": 9, "num_props": t.num_props}
+
+    def pre(self):
+        self.task.pre_physics_step(self.actions)
+
+    def post(self):
+        self.task.post_physics_step()
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from oracle import franka_cabinet_oracle as fo
+
+        spec = fo.FrankaCabinetSpec()
+        env_pos = torch.zeros(n, 3)
+        st = workloads.franka_cabinet_state(n, env_pos, torch.tensor(spec.franka_local_grasp_pos), device="cpu", seed=1234)
+        st["rfinger_pos"] = st["lfinger_pos"]
+        b = fo.FrankaCabinetBuffers(torch.zeros(n, 23), torch.zeros(n), st["reset"].clone(), st["progress"].clone(), st["prev_actions"].clone(),
+                                    st["targets"].clone(), torch.zeros(n, 4), torch.zeros(n, 3), torch.zeros(n, 4), torch.zeros(n, 3))
+        lo = torch.tensor([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973, 0.0, 0.0])
+        hi = torch.tensor([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973, 0.04, 0.04])
+        speed = torch.ones(9)
+        speed[7:] = 0.1
+        pp, pr = torch.zeros(n * 4, 3), torch.zeros(n * 4, 4)
+
+        def step():
+            fo.pre_physics(spec, b, st["actions"], lo, hi, speed, lambda ids: torch.rand(len(ids), 9), num_props=4, default_prop_pos=pp,
+                           default_prop_rot=pr)
+            fo.post_physics(spec, b, st, lo, hi)
+
+        return step
+
+
 class AnymalFlatBench:
     """Anymal on flat ground (obs 48, 6-term reward, non-sticky done, position targets)."""
 
@@ -558,9 +611,9 @@ class AnymalFlatBench:
         return step
 
 
-ADAPTERS = {"Crazyflie": CrazyflieBench, "Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
-DEFAULT_ENVS = {"Crazyflie": 1 << 20, "Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
-CPU_ENVS = {"Crazyflie": 1 << 18, "Ingenuity": 1 << 18, "BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
+ADAPTERS = {"FrankaCabinet": FrankaCabinetBench, "Crazyflie": CrazyflieBench, "Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
+DEFAULT_ENVS = {"FrankaCabinet": 1 << 20, "Crazyflie": 1 << 20, "Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
+CPU_ENVS = {"FrankaCabinet": 1 << 18, "Crazyflie": 1 << 18, "Ingenuity": 1 << 18, "BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
 def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:

@@ -901,6 +901,101 @@ int oige_cartpole_reset_idx(const oige_cartpole_params* params, const oige_cartp
                             const oige_cartpole_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
                             oige_stream_t stream);
 
+/* ------------------------------------------------------------------ FrankaCabinet
+ * tasks/franka_cabinet.py.  Scalars: cfg/task/FrankaCabinet.yaml:8-32, franka_cabinet.py:52-53,257-279.
+ * The per-env tensors the reference builds with .repeat((num_envs, 1)) (:257-275: local grasp poses and the four axes) have
+ * identical rows; they cross the ABI as the row.                                                                 */
+#define OIGE_FRANKA_DOFS 9
+#define OIGE_FRANKA_OBS 23
+#define OIGE_CABINET_DOFS 4
+
+typedef struct oige_franka_cabinet_params {
+  float action_scale;                /* 7.5 */
+  float dof_vel_scale;               /* 0.1 */
+  float dt;                          /* 1/60 (:53) */
+  float clip_actions;                /* with OIGE_PRE_CLAMP_ACTIONS */
+  float dist_reward_scale, rot_reward_scale, around_handle_reward_scale, open_reward_scale;
+  float finger_dist_reward_scale, action_penalty_scale, finger_close_reward_scale;
+  float reserved0;
+  float franka_local_grasp_pos[3];   /* (:253-257) */
+  float franka_local_grasp_rot[4];   /* wxyz (:258) */
+  float drawer_local_grasp_pos[3];   /* (0.3, 0.01, 0) (:260-261) */
+  float drawer_local_grasp_rot[4];   /* (1, 0, 0, 0) (:262) */
+  float gripper_forward_axis[3];     /* (0, 0, 1) (:264) */
+  float drawer_inward_axis[3];       /* (-1, 0, 0) (:267) */
+  float gripper_up_axis[3];          /* (0, 1, 0) (:270) */
+  float drawer_up_axis[3];           /* (0, 0, 1) (:273) */
+  float dof_lower[OIGE_FRANKA_DOFS]; /* (:421-422) */
+  float dof_upper[OIGE_FRANKA_DOFS];
+  float dof_speed_scales[OIGE_FRANKA_DOFS]; /* 1, gripper joints 0.1 (:423-424) */
+  float default_dof_pos[OIGE_FRANKA_DOFS];  /* (:277-279) */
+  int32_t max_episode_length;        /* 500 */
+  int32_t num_props;                 /* 4; 0 = no prop rows */
+} oige_franka_cabinet_params;
+
+typedef struct oige_franka_cabinet_state {  /* view getters of get_observations (:284-289, :336-337), read-only */
+  const float* hand_pos;        /* (N,3) world */
+  const float* hand_rot;        /* (N,4) wxyz */
+  const float* drawer_pos;      /* (N,3) */
+  const float* drawer_rot;      /* (N,4) */
+  const float* franka_dof_pos;  /* (N,9) */
+  const float* franka_dof_vel;  /* (N,9) */
+  const float* cabinet_dof_pos; /* (N,4): column 3 = drawer_top_joint */
+  const float* cabinet_dof_vel; /* (N,4) */
+  const float* lfinger_pos;     /* (N,3) */
+  const float* rfinger_pos;     /* (N,3): the reference passes the LEFT finger view here too (:337) */
+} oige_franka_cabinet_state;
+
+typedef struct oige_franka_cabinet_buffers {
+  float* obs_buf;             /* (N,23) */
+  float* rew_buf;             /* (N,) */
+  int64_t* reset_buf;         /* (N,) sticky (:470-473) */
+  int64_t* progress_buf;      /* (N,) */
+  float* actions;             /* (N,9): written by pre_physics (:368), read by the reward */
+  float* franka_dof_targets;  /* (N,9) */
+  float* franka_grasp_rot;    /* (N,4) or NULL: the task attributes of :293-296, written by the obs stage */
+  float* franka_grasp_pos;    /* (N,3) or NULL */
+  float* drawer_grasp_rot;    /* (N,4) or NULL */
+  float* drawer_grasp_pos;    /* (N,3) or NULL */
+  int32_t* reset_workspace;   /* as oige_locomotion_buffers.reset_workspace */
+} oige_franka_cabinet_buffers;
+
+/* post_physics_step: progress += 1, get_observations (:283-358, incl. compute_grasp_transforms :475-494),
+ * calculate_metrics (:439-466 -> compute_franka_reward :496-601), is_done (:468-473).  `stages` as for locomotion.      */
+int oige_franka_cabinet_post_physics(const oige_franka_cabinet_params* params, const oige_franka_cabinet_state* state,
+                                     const oige_franka_cabinet_buffers* buffers, int64_t num_envs, uint32_t stages,
+                                     oige_stream_t stream);
+
+typedef struct oige_franka_cabinet_reset_io {
+  const float* u_dof;            /* NULL, or (n,9) pre-drawn U[0,1): the draw of :382 */
+  const float* default_prop_pos; /* (N*num_props,3) (:430), may be NULL when num_props == 0 */
+  const float* default_prop_rot; /* (N*num_props,4) */
+  uint64_t seed;
+  uint64_t step;
+  int64_t* env_ids;              /* out (N,) ascending == reset_buf.nonzero() */
+  int64_t* count;                /* out device scalar */
+  float* dof_pos_out;            /* out (n,9): also the rows of set_joint_position_targets(..., indices) (:408) */
+  float* dof_vel_out;            /* out (n,9) zeros */
+  float* cabinet_dof_pos_out;    /* out (n,4) zeros (:393-398) */
+  float* cabinet_dof_vel_out;    /* out (n,4) zeros */
+  int64_t* prop_ids;             /* out (n*num_props,) = prop_indices[env_ids].flatten() (:403-405) */
+  int64_t* prop_count;           /* out device scalar = count * num_props */
+  float* prop_pos_out;           /* out (n*num_props,3) */
+  float* prop_rot_out;           /* out (n*num_props,4) */
+} oige_franka_cabinet_reset_io;
+
+/* pre_physics_step (:360-373): compaction, reset_idx of the flagged envs, actions clone, then for ALL envs (the reset ones
+ * start from their new positions) targets = clamp(targets + speed_scales * dt * actions * action_scale, lower, upper).      */
+int oige_franka_cabinet_pre_physics(const oige_franka_cabinet_params* params, const float* actions_in,
+                                    const oige_franka_cabinet_buffers* buffers,
+                                    const oige_franka_cabinet_reset_io* reset_io, int64_t num_envs, uint32_t flags,
+                                    oige_stream_t stream);
+
+/* reset_idx(env_ids) with caller-provided ids (:375-414).                                                          */
+int oige_franka_cabinet_reset_idx(const oige_franka_cabinet_params* params, const oige_franka_cabinet_buffers* buffers,
+                                  const oige_franka_cabinet_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                                  oige_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -241,6 +241,32 @@ class IngenuityResetIO(C.Structure):
                            "target_ids", "target_count", "ball_pos_out", "ball_rot_out")]
 
 
+class FrankaCabinetParams(C.Structure):
+    _fields_ = [(n, _f) for n in ("action_scale", "dof_vel_scale", "dt", "clip_actions", "dist_reward_scale", "rot_reward_scale",
+                                  "around_handle_reward_scale", "open_reward_scale", "finger_dist_reward_scale",
+                                  "action_penalty_scale", "finger_close_reward_scale", "reserved0")] + [
+        ("franka_local_grasp_pos", _f * 3), ("franka_local_grasp_rot", _f * 4), ("drawer_local_grasp_pos", _f * 3),
+        ("drawer_local_grasp_rot", _f * 4), ("gripper_forward_axis", _f * 3), ("drawer_inward_axis", _f * 3),
+        ("gripper_up_axis", _f * 3), ("drawer_up_axis", _f * 3), ("dof_lower", _f * 9), ("dof_upper", _f * 9),
+        ("dof_speed_scales", _f * 9), ("default_dof_pos", _f * 9), ("max_episode_length", C.c_int32), ("num_props", C.c_int32)]
+
+
+class FrankaCabinetState(C.Structure):
+    _fields_ = [(n, _fp) for n in ("hand_pos", "hand_rot", "drawer_pos", "drawer_rot", "franka_dof_pos", "franka_dof_vel",
+                                   "cabinet_dof_pos", "cabinet_dof_vel", "lfinger_pos", "rfinger_pos")]
+
+
+class FrankaCabinetBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "actions", "franka_dof_targets",
+                                   "franka_grasp_rot", "franka_grasp_pos", "drawer_grasp_rot", "drawer_grasp_pos", "reset_workspace")]
+
+
+class FrankaCabinetResetIO(C.Structure):
+    _fields_ = [("u_dof", _fp), ("default_prop_pos", _fp), ("default_prop_rot", _fp), ("seed", C.c_uint64), ("step", C.c_uint64)] + [
+        (n, _fp) for n in ("env_ids", "count", "dof_pos_out", "dof_vel_out", "cabinet_dof_pos_out", "cabinet_dof_vel_out", "prop_ids",
+                           "prop_count", "prop_pos_out", "prop_rot_out")]
+
+
 class CrazyflieParams(C.Structure):
     _fields_ = [("motor_tau_up", _f), ("motor_tau_down", _f), ("prop_max_rot", _f), ("clip_actions", _f), ("thrust_max", _f * 4),
                 ("max_episode_length", C.c_int32), ("reserved0", C.c_int32 * 3)]
@@ -346,6 +372,12 @@ SIGNATURES = {
                                            C.c_int64, C.c_int64, _P]),
     "oige_crazyflie_set_targets": (C.c_int, [C.POINTER(CrazyflieParams), C.POINTER(CrazyflieBuffers), C.POINTER(CrazyflieResetIO),
                                              C.c_int64, C.c_int64, _P]),
+    "oige_franka_cabinet_post_physics": (C.c_int, [C.POINTER(FrankaCabinetParams), C.POINTER(FrankaCabinetState),
+                                                   C.POINTER(FrankaCabinetBuffers), C.c_int64, C.c_uint32, _P]),
+    "oige_franka_cabinet_pre_physics": (C.c_int, [C.POINTER(FrankaCabinetParams), _P, C.POINTER(FrankaCabinetBuffers),
+                                                  C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_uint32, _P]),
+    "oige_franka_cabinet_reset_idx": (C.c_int, [C.POINTER(FrankaCabinetParams), C.POINTER(FrankaCabinetBuffers),
+                                                C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_int64, _P]),
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "oige_dr_noise_count": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_dr_noise_apply": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),

@@ -345,3 +345,58 @@ def load_crazyflie_state(task, st: Dict[str, Tensor]) -> None:
     task._episode_sums.copy_(st["episode_sums"].to(dev))
     task.progress_buf.copy_(st["progress"].to(dev))
     task.reset_buf.copy_(st["reset"].to(dev))
+
+
+def _rotate(q: Tensor, v: Tensor) -> Tensor:
+    xyz = q[:, 1:]
+    t = torch.linalg.cross(xyz, v) * 2
+    return v + q[:, 0:1] * t + torch.linalg.cross(xyz, t)
+
+
+def franka_cabinet_state(n: int, env_pos: Tensor, local_grasp_pos: Tensor, device="cpu", seed: int = 1234) -> Dict[str, Tensor]:
+    """FrankaCabinet: the hand within ~0.2 m of the drawer handle, a quarter of the envs within a few
+    centimetres (the d <= 0.02 / 0.03 branches), drawer joint U(0, 0.45) (13 % open beyond 0.39 -> reset), fingers around the
+    handle height, progress up to the 500-step episode."""
+    g = _gen(device, seed)
+    f = dict(device=device, dtype=torch.float32, generator=g)
+    env_pos = env_pos.to(device)
+    unit = lambda: torch.nn.functional.normalize(torch.randn(n, 4, **f), dim=-1).contiguous()
+    hand_rot, drawer_rot = unit(), unit()
+    drawer_rot = torch.where(torch.rand(n, 1, **f) < 0.5, torch.tensor([1.0, 0.0, 0.0, 0.0], device=device), drawer_rot).contiguous()
+    drawer_pos = (env_pos + torch.tensor([0.35, 0.0, 0.4], device=device) + torch.randn(n, 3, **f) * 0.05).contiguous()
+    drawer_grasp = drawer_pos + _rotate(drawer_rot, torch.tensor([0.3, 0.01, 0.0], device=device).repeat(n, 1))
+    spread = torch.where(torch.rand(n, 1, **f) < 0.25, torch.tensor(0.012, device=device), torch.tensor(0.12, device=device))
+    franka_grasp = drawer_grasp + torch.randn(n, 3, **f) * spread
+    hand_pos = (franka_grasp - _rotate(hand_rot, local_grasp_pos.to(device).reshape(1, 3).repeat(n, 1))).contiguous()
+    lo = torch.tensor([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973, 0.0, 0.0], device=device)
+    hi = torch.tensor([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973, 0.04, 0.04], device=device)
+    lf = franka_grasp + torch.randn(n, 3, **f) * 0.03
+    rf = franka_grasp + torch.randn(n, 3, **f) * 0.03
+    return dict(
+        hand_pos=hand_pos, hand_rot=hand_rot, drawer_pos=drawer_pos, drawer_rot=drawer_rot,
+        franka_dof_pos=(lo + (hi - lo) * torch.rand(n, 9, **f)).contiguous(), franka_dof_vel=torch.randn(n, 9, **f),
+        cabinet_dof_pos=torch.rand(n, 4, **f) * 0.45, cabinet_dof_vel=torch.randn(n, 4, **f) * 0.3,
+        lfinger_pos=lf.contiguous(), rfinger_pos=rf.contiguous(),
+        actions=torch.rand(n, 9, **f) * 2.0 - 1.0, prev_actions=torch.rand(n, 9, **f) * 2.0 - 1.0,
+        targets=(lo + (hi - lo) * torch.rand(n, 9, **f)).contiguous(),
+        progress=torch.randint(0, 498, (n,), device=device, generator=g, dtype=torch.int64),
+        reset=(torch.rand(n, **f) < 0.03).long(),
+    )
+
+
+def load_franka_cabinet_state(task, st: Dict[str, Tensor]) -> None:
+    dev, fr, cab = task.device, task._frankas, task._cabinets
+    fr._hands.positions.copy_(st["hand_pos"].to(dev))
+    fr._hands.orientations.copy_(st["hand_rot"].to(dev))
+    cab._drawers.positions.copy_(st["drawer_pos"].to(dev))
+    cab._drawers.orientations.copy_(st["drawer_rot"].to(dev))
+    fr.joint_positions.copy_(st["franka_dof_pos"].to(dev))
+    fr.joint_velocities.copy_(st["franka_dof_vel"].to(dev))
+    cab.joint_positions.copy_(st["cabinet_dof_pos"].to(dev))
+    cab.joint_velocities.copy_(st["cabinet_dof_vel"].to(dev))
+    fr._lfingers.positions.copy_(st["lfinger_pos"].to(dev))
+    fr._rfingers.positions.copy_(st["rfinger_pos"].to(dev))
+    task.actions.copy_(st["prev_actions"].to(dev))
+    task.franka_dof_targets.copy_(st["targets"].to(dev))
+    task.progress_buf.copy_(st["progress"].to(dev))
+    task.reset_buf.copy_(st["reset"].to(dev))

@@ -150,6 +150,17 @@ TASK_DEFAULTS["Crazyflie"] = {
     "sim": dict(_SIM, dt=0.01, gravity=[0.0, 0.0, -9.81]),
 }
 
+# cfg/task/FrankaCabinet.yaml:7-32
+TASK_DEFAULTS["FrankaCabinet"] = {
+    "name": "FrankaCabinet",
+    "env": {"numEnvs": 4096, "envSpacing": 3.0, "episodeLength": 500, "enableDebugVis": False, "clipObservations": 5.0,
+            "clipActions": 1.0, "controlFrequencyInv": 2, "startPositionNoise": 0.0, "startRotationNoise": 0.0, "numProps": 4,
+            "aggregateMode": 3, "actionScale": 7.5, "dofVelocityScale": 0.1, "actionPenaltyScale": 0.01,
+            "aroundHandleRewardScale": 10.0, "distRewardScale": 2.0, "fingerCloseRewardScale": 10.0,
+            "fingerDistRewardScale": 100.0, "openRewardScale": 7.5, "rotRewardScale": 0.5},
+    "sim": dict(_SIM, dt=0.0083, gravity=[0.0, 0.0, -9.81]),
+}
+
 # cfg/task/AnymalTerrain.yaml:5-103
 TASK_DEFAULTS["AnymalTerrain"] = {
     "name": "AnymalTerrain",

@@ -251,3 +251,20 @@ HELPER_NAMES = (
     "quat_rotate quat_rotate_inverse quat_axis quat_from_angle_axis get_basis_vector copysign get_euler_xyz "
     "compute_heading_and_up compute_rot"
 ).split()
+
+
+def tf_combine(q1: Tensor, t1: Tensor, q2: Tensor, t2: Tensor) -> Tuple[Tensor, Tensor]:
+    """Compose two rigid transforms: (q1 * q2, q1 applied to t2, plus t1).  Restated omni helper (parity unpinned);
+    call sites: tasks/franka_cabinet.py:253, :487-492."""
+    return quat_mul(q1, q2), quat_apply(q1, t2) + t1
+
+
+def tf_vector(q: Tensor, v: Tensor) -> Tensor:
+    """Rotate a vector by a quaternion.  Call sites: tasks/franka_cabinet.py:532-535."""
+    return quat_apply(q, v)
+
+
+def tf_inverse(q: Tensor, t: Tensor) -> Tuple[Tensor, Tensor]:
+    """Inverse of a rigid transform.  Call site: tasks/franka_cabinet.py:250 (set-up only)."""
+    q_inv = quat_conjugate(q)
+    return q_inv, -quat_apply(q_inv, t)

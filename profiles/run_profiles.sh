@@ -3,7 +3,7 @@
 # Usage: bash profiles/run_profiles.sh <tag>     outputs under gpurun_out/prof_<tag>/
 set -u
 TAG=${1:-r01}
-TASKS=${TASKS:-"Ant Humanoid ShadowHand AnymalTerrain Anymal AllegroHand Quadcopter BallBalance Ingenuity Crazyflie"}
+TASKS=${TASKS:-"Ant Humanoid ShadowHand AnymalTerrain Anymal AllegroHand Quadcopter BallBalance Ingenuity Crazyflie FrankaCabinet"}
 PMC=${PMC:-1}
 OUT=/tmp/prof_$TAG
 mkdir -p $OUT

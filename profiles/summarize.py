@@ -18,7 +18,7 @@ from collections import defaultdict
 
 DEFAULT_ENVS = {"Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18, "Anymal": 1 << 20,
                 "AllegroHand": 1 << 20, "Quadcopter": 1 << 20, "BallBalance": 1 << 20, "Ingenuity": 1 << 20,
-                "Crazyflie": 1 << 20}  # bench.py defaults
+                "Crazyflie": 1 << 20, "FrankaCabinet": 1 << 20}  # bench.py defaults
 
 
 def short(name: str) -> str:
@@ -75,7 +75,8 @@ def main() -> None:
                                   "anymal_command_norm_kernel", "scan_groups_kernel"],
                 "Anymal": ["anymal_flat_post_kernel"], "AllegroHand": ["allegro_post_kernel"],
                 "Quadcopter": ["quadcopter_post_kernel"], "BallBalance": ["ball_balance_post_kernel"],
-                "Ingenuity": ["ingenuity_post_kernel"], "Crazyflie": ["crazyflie_post_kernel"]}
+                "Ingenuity": ["ingenuity_post_kernel"], "Crazyflie": ["crazyflie_post_kernel"],
+                "FrankaCabinet": ["franka_cabinet_post_kernel"]}
     traffic = {}
     for task, ks in pmc.items():
         fetch = write = 0.0

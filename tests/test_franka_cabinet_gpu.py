@@ -1,0 +1,160 @@
+"""-m gpu parity tests: HIP FrankaCabinet path (through the C ABI) vs the CPU oracle (pinned to tasks/franka_cabinet.py by
+tests/test_oracle_pinned_franka_cabinet.py).  Bar: reset flags, id lists, progress bit-exact; fp32 observations, rewards,
+grasp transforms, targets within 1e-5 rel / 1e-6 abs."""
+import pytest
+import torch
+
+from helpers import assert_close, assert_equal, make_task
+from omniisaacgymenvs_amd.sim import workloads
+from oracle import franka_cabinet_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaded(n, seed=1234, right_finger=False):
+    env, task = make_task("FrankaCabinet", n)
+    task.use_right_finger_view = right_finger
+    st = workloads.franka_cabinet_state(n, task._env_pos.cpu(), task.franka_local_grasp_pos[0].cpu(), device="cpu", seed=seed)
+    if n > 12:
+        st["progress"][:3] = torch.tensor([496, 497, 498])
+        st["cabinet_dof_pos"][3:9, 3] = torch.tensor([0.0099, 0.0101, 0.1999, 0.2001, 0.3899, 0.3901])
+    workloads.load_franka_cabinet_state(task, st)
+    if not right_finger:
+        st = dict(st, rfinger_pos=st["lfinger_pos"])  # what the reference's binding feeds the reward (:337)
+    return env, task, st
+
+
+def _spec(task) -> fo.FrankaCabinetSpec:
+    return fo.FrankaCabinetSpec(franka_local_grasp_pos=task.franka_local_grasp_pos[0].tolist(),
+                                franka_local_grasp_rot=task.franka_local_grasp_rot[0].tolist(), num_props=task.num_props)
+
+
+def _oracle_buffers(task) -> fo.FrankaCabinetBuffers:
+    c = lambda t: t.detach().cpu().clone()
+    return fo.FrankaCabinetBuffers(c(task.obs_buf), c(task.rew_buf), c(task.reset_buf), c(task.progress_buf), c(task.actions),
+                                   c(task.franka_dof_targets), c(task.franka_grasp_rot), c(task.franka_grasp_pos), c(task.drawer_grasp_rot),
+                                   c(task.drawer_grasp_pos))
+
+
+def _limits(task):
+    return task.franka_dof_lower_limits.cpu(), task.franka_dof_upper_limits.cpu()
+
+
+@pytest.mark.parametrize("n", [1, 40, 64, 257, 4096])
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("right_finger", [False, True])
+def test_post_physics_matches_oracle(n, fused, right_finger):
+    env, task, st = _loaded(n, right_finger=right_finger)
+    task.fused = fused
+    spec, b = _spec(task), _oracle_buffers(task)
+    lo, hi = _limits(task)
+    fo.post_physics(spec, b, st, lo, hi)
+    obs, rew, reset, _ = task.post_physics_step()
+    torch.cuda.synchronize()
+    assert_equal(reset, b.reset_buf, "reset_buf")
+    assert_equal(task.progress_buf, b.progress_buf, "progress_buf")
+    assert_close(obs, b.obs_buf, "obs_buf")
+    for k in ("franka_grasp_rot", "franka_grasp_pos", "drawer_grasp_rot", "drawer_grasp_pos"):
+        assert_close(getattr(task, k), getattr(b, k), k)
+    # reward: the two distance thresholds and the finger-height comparisons may flip within rounding of d / z
+    d = torch.norm(b.franka_grasp_pos - b.drawer_grasp_pos, dim=-1)
+    dz = torch.minimum((st["lfinger_pos"][:, 2] - b.drawer_grasp_pos[:, 2]).abs(), (st["rfinger_pos"][:, 2] - b.drawer_grasp_pos[:, 2]).abs())
+    ok = ((d - 0.02).abs() > 1e-6) & ((d - 0.03).abs() > 1e-6) & (dz > 1e-6)
+    assert int(ok.sum()) >= n - 2
+    assert_close(rew[ok], b.rew_buf[ok], "rew_buf")
+    if n >= 4096:
+        assert int((d <= 0.02).sum()) > 20 and int(((d > 0.02) & (d <= 0.03)).sum()) > 20
+        around = (st["lfinger_pos"][:, 2] > b.drawer_grasp_pos[:, 2]) & (st["rfinger_pos"][:, 2] < b.drawer_grasp_pos[:, 2])
+        assert (int(around.sum()) > 100) == right_finger
+    if n > 12:
+        assert int(reset[2]) == 1 and int(reset[1]) == int(st["reset"][1])   # progress 498 -> 499 == max - 1; 497 -> 498 not yet
+        assert int(reset[7]) == int(st["reset"][7]) and int(reset[8]) == 1
+
+
+@pytest.mark.parametrize("n", [1, 64, 300, 5000])
+@pytest.mark.parametrize("clamp", [False, True])
+def test_sync_free_pre_physics_matches_oracle(n, clamp):
+    env, task, st = _loaded(n)
+    for v in (task._frankas, task._cabinets, task._props):
+        v.apply_resets = False
+    if n >= 64:
+        task.reset_buf[: n // 3] = 1
+    spec, b = _spec(task), _oracle_buffers(task)
+    lo, hi = _limits(task)
+    actions = torch.rand(n, 9, generator=torch.Generator().manual_seed(5)) * 3 - 1.5
+    task.clamp_actions_in_kernel = clamp
+    want_actions = torch.clamp(actions, -task.clip_actions, task.clip_actions) if clamp else actions
+    task.pre_physics_step(actions.to(task.device))
+    torch.cuda.synchronize()
+    o = task._reset_out
+    k = int(o["count"].item())
+    u_dev = (o["dof_pos"][:k].cpu() - torch.tensor(fo.FRANKA_DEFAULT_DOF_POS)) / 0.25 + 0.5  # recover the in-kernel draws where unclamped
+    ids, rows = fo.pre_physics(spec, b, want_actions, lo, hi, task.franka_dof_speed_scales.cpu(), lambda i: u_dev.clone(),
+                               num_props=task.num_props, default_prop_pos=task.default_prop_pos.cpu(), default_prop_rot=task.default_prop_rot.cpu())
+    assert k == len(ids)
+    assert_equal(o["env_ids"][:k], ids, "env ids == reset_buf.nonzero()")
+    assert_equal(task.reset_buf, b.reset_buf, "reset_buf")
+    assert_equal(task.progress_buf, b.progress_buf, "progress_buf")
+    assert_equal(task.actions, b.actions, "actions")
+    assert_close(task.franka_dof_targets, b.franka_dof_targets, "franka_dof_targets")
+    assert_close(task._frankas.joint_position_targets, b.franka_dof_targets, "targets handed to the view")
+    if rows is not None:
+        dp = o["dof_pos"][:k].cpu()
+        assert bool(((dp >= lo) & (dp <= hi)).all())
+        inside = (dp > lo + 1e-6) & (dp < hi - 1e-6)
+        assert bool(((u_dev >= -1e-5) & (u_dev < 1.0 + 1e-5))[inside].all()), "in-kernel draws are U[0,1)"
+        assert float(u_dev[inside].mean()) == pytest.approx(0.5, abs=0.05 if k > 500 else 0.3)
+        assert_close(o["dof_pos"][:k], rows["dof_pos"], "dof_pos rows")
+        assert float(o["dof_vel"][:k].abs().max()) == 0.0 and float(o["cabinet_dof_pos"][:k].abs().max()) == 0.0
+        P = task.num_props
+        assert int(o["prop_count"].item()) == k * P
+        assert_equal(o["prop_ids"][: k * P], rows["prop_ids"], "prop ids")
+        assert_equal(o["prop_pos"][: k * P], rows["prop_pos"], "prop_pos rows")
+        assert_equal(o["prop_rot"][: k * P], rows["prop_rot"], "prop_rot rows")
+
+
+def test_reference_flow_replays_torch_rng():
+    n = 500
+    env, task, st = _loaded(n)
+    task.sync_free = False
+    task.reset_buf[::7] = 1
+    spec, b = _spec(task), _oracle_buffers(task)
+    lo, hi = _limits(task)
+    actions = torch.rand(n, 9, generator=torch.Generator().manual_seed(6)) * 2 - 1
+    torch.manual_seed(77)
+    task.pre_physics_step(actions.to(task.device))
+    torch.cuda.synchronize()
+    torch.manual_seed(77)
+    ids, rows = fo.pre_physics(spec, b, actions, lo, hi, task.franka_dof_speed_scales.cpu(),
+                               lambda i: torch.rand((len(i), 9), device=task.device).cpu(), num_props=task.num_props,
+                               default_prop_pos=task.default_prop_pos.cpu(), default_prop_rot=task.default_prop_rot.cpu())
+    assert_equal(task.reset_buf, b.reset_buf, "reset_buf")
+    assert_equal(task.progress_buf, b.progress_buf, "progress_buf")
+    assert_close(task.franka_dof_targets, b.franka_dof_targets, "franka_dof_targets")
+    assert_close(task._frankas.joint_positions[ids.to(task.device)], rows["dof_pos"], "joint positions written through the setter")
+    assert float(task._cabinets.joint_positions[ids.to(task.device)].abs().max()) == 0.0
+    pid = rows["prop_ids"].to(task.device)
+    assert_equal(task._props.positions[pid], rows["prop_pos"], "prop poses restored")
+
+
+def test_full_size_properties():
+    n = 1 << 20
+    env, task, st = _loaded(n)
+    obs, rew, reset, _ = task.post_physics_step()
+    torch.cuda.synchronize()
+    assert_equal(obs[:, 21], st["cabinet_dof_pos"][:, 3], "obs drawer joint position")
+    assert_close(obs[:, 9:18], st["franka_dof_vel"] * 0.1, "obs joint velocities")
+    assert_close(obs[:, 18:21], task.drawer_grasp_pos - task.franka_grasp_pos, "to_target == difference of the grasp points")
+    assert float((task.franka_grasp_rot.norm(dim=-1) - 1).abs().max()) < 1e-5
+    want = reset.nonzero().squeeze(-1).clone()
+    assert bool((reset[(st["cabinet_dof_pos"][:, 3] > 0.39).to(task.device)] == 1).all())
+    for v in (task._frankas, task._cabinets, task._props):
+        v.apply_resets = False
+    task.pre_physics_step(st["actions"].to(task.device))
+    torch.cuda.synchronize()
+    o = task._reset_out
+    assert int(o["count"].item()) == want.numel() and want.numel() > 0
+    assert_equal(o["env_ids"][: want.numel()], want, "env ids == nonzero()")
+    assert int(task.reset_buf.sum().item()) == 0 and int(task.progress_buf[want].sum().item()) == 0
+    lo, hi = task.franka_dof_lower_limits, task.franka_dof_upper_limits
+    assert bool(((task.franka_dof_targets >= lo) & (task.franka_dof_targets <= hi)).all())
