@@ -996,6 +996,26 @@ int oige_franka_cabinet_reset_idx(const oige_franka_cabinet_params* params, cons
                                   const oige_franka_cabinet_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
                                   oige_stream_t stream);
 
+/* ------------------------------------------------------------------ Episode-stat observer
+ * utils/rlgames/rlgames_utils.py:52-85 (RLGPUAlgoObserver.process_infos / after_print_stats).                     */
+#define OIGE_OBSERVER_MAX_KEYS 64
+
+typedef struct oige_observer_batch {  /* one step's infos["episode"]: per key a device pointer to `length` floats */
+  const float* values[OIGE_OBSERVER_MAX_KEYS];
+  int32_t lengths[OIGE_OBSERVER_MAX_KEYS]; /* 1 for a scalar / 0-dim tensor (:80-81), n for a 1-D tensor */
+  int32_t num_keys;
+  int32_t reserved0;
+} oige_observer_batch;
+
+/* process_infos (:52-56): sums[k] += sum(values[k][0:length]) in f64, counts[k] += length.  One launch per step.     */
+int oige_observer_accumulate(const oige_observer_batch* batch, double* sums /* (num_keys,) */,
+                             int64_t* counts /* (num_keys,) */, oige_stream_t stream);
+
+/* after_print_stats (:73-85): means_out[k] = (float)(sums[k] / counts[k]) (nan when nothing was appended, as torch.mean of
+ * an empty tensor); clear != 0 also zeroes sums and counts (ep_infos.clear(), :85).                                */
+int oige_observer_means(double* sums, int64_t* counts, float* means_out /* (num_keys,) */, int32_t num_keys,
+                        int32_t clear, oige_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -267,6 +267,14 @@ class FrankaCabinetResetIO(C.Structure):
                            "prop_count", "prop_pos_out", "prop_rot_out")]
 
 
+OBSERVER_MAX_KEYS = 64
+
+
+class ObserverBatch(C.Structure):
+    _fields_ = [("values", _fp * OBSERVER_MAX_KEYS), ("lengths", C.c_int32 * OBSERVER_MAX_KEYS), ("num_keys", C.c_int32),
+                ("reserved0", C.c_int32)]
+
+
 class CrazyflieParams(C.Structure):
     _fields_ = [("motor_tau_up", _f), ("motor_tau_down", _f), ("prop_max_rot", _f), ("clip_actions", _f), ("thrust_max", _f * 4),
                 ("max_episode_length", C.c_int32), ("reserved0", C.c_int32 * 3)]
@@ -378,6 +386,8 @@ SIGNATURES = {
                                                   C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_uint32, _P]),
     "oige_franka_cabinet_reset_idx": (C.c_int, [C.POINTER(FrankaCabinetParams), C.POINTER(FrankaCabinetBuffers),
                                                 C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_int64, _P]),
+    "oige_observer_accumulate": (C.c_int, [C.POINTER(ObserverBatch), _P, _P, _P]),
+    "oige_observer_means": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "oige_dr_noise_count": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_dr_noise_apply": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
