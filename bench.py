@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- fused obs+reward+reset env-steps/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter|BallBalance|Ingenuity|Crazyflie|FrankaCabinet]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter|BallBalance|Ingenuity|Crazyflie|FrankaCabinet|TomoDJCabinet|TomoSPCCabinet]
 
 One "step" = one pre_physics_step (reset-id compaction, reset of the flagged envs, action scaling /
 PD torques) + one post_physics_step (progress, obs, reward, done[, in-step reset]) over a batch of
@@ -517,17 +517,19 @@ class FrankaCabinetBench:
         from helpers import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
-        self.env, self.task = make_task("FrankaCabinet", n, device=dev, seed=seed)
+        self.env, self.task = make_task(name, n, device=dev, seed=seed)
         t = self.task
-        st = workloads.franka_cabinet_state(n, t._env_pos, t.franka_local_grasp_pos[0], device=dev, seed=seed)
+        st = workloads.franka_cabinet_state(n, t._env_pos, t.franka_local_grasp_pos[0], device=dev, seed=seed, num_dofs=t.NUM_DOFS,
+                                            drawer_scale=0.45 if name == "FrankaCabinet" else 0.22)
         workloads.load_franka_cabinet_state(t, st)
         for v in (t._frankas, t._cabinets, t._props):
             v.apply_resets = False
         self.actions = st["actions"]
-        self.post_bytes = 220 + 168  # csrc/franka_cabinet.hip header
+        D = t.NUM_DOFS
+        self.post_bytes = (112 + 12 * D) + (76 + 4 * (2 * D + 5))  # csrc/franka_cabinet.hip header: 220 + 168 at 9 DOFs
         self.kernel = "franka_cabinet_post_kernel"
-        self.workload = f"FrankaCabinet grasp transforms+obs(23)+reward+reset fused, {n} envs per GPU, synthetic hand/drawer/DOF state"
-        self.extra_cfg = {"num_dof": 9, "num_props": t.num_props}
+        self.workload = f"{name} grasp transforms+obs({2 * D + 5})+reward+reset fused, {n} envs per GPU, synthetic hand/drawer/DOF state"
+        self.extra_cfg = {"num_dof": D, "num_props": t.num_props}
 
     def pre(self):
         self.task.pre_physics_step(self.actions)
@@ -543,20 +545,23 @@ class FrankaCabinetBench:
         from omniisaacgymenvs_amd.sim import workloads
         from oracle import franka_cabinet_oracle as fo
 
-        spec = fo.FrankaCabinetSpec()
+        spec = {"FrankaCabinet": fo.FrankaCabinetSpec, "TomoDJCabinet": fo.tomodj_spec, "TomoSPCCabinet": fo.tomospc_spec}[name]()
+        D = spec.num_dofs
         env_pos = torch.zeros(n, 3)
-        st = workloads.franka_cabinet_state(n, env_pos, torch.tensor(spec.franka_local_grasp_pos), device="cpu", seed=1234)
-        st["rfinger_pos"] = st["lfinger_pos"]
-        b = fo.FrankaCabinetBuffers(torch.zeros(n, 23), torch.zeros(n), st["reset"].clone(), st["progress"].clone(), st["prev_actions"].clone(),
+        st = workloads.franka_cabinet_state(n, env_pos, torch.tensor(spec.franka_local_grasp_pos), device="cpu", seed=1234, num_dofs=D,
+                                            drawer_scale=0.45 if name == "FrankaCabinet" else 0.22)
+        if name == "FrankaCabinet":
+            st["rfinger_pos"] = st["lfinger_pos"]
+        b = fo.FrankaCabinetBuffers(torch.zeros(n, 2 * D + 5), torch.zeros(n), st["reset"].clone(), st["progress"].clone(), st["prev_actions"].clone(),
                                     st["targets"].clone(), torch.zeros(n, 4), torch.zeros(n, 3), torch.zeros(n, 4), torch.zeros(n, 3))
-        lo = torch.tensor([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973, 0.0, 0.0])
-        hi = torch.tensor([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973, 0.04, 0.04])
-        speed = torch.ones(9)
-        speed[7:] = 0.1
+        lo = torch.tensor([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973, 0.0, 0.0])[9 - D:]
+        hi = torch.tensor([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973, 0.04, 0.04])[9 - D:]
+        speed = torch.ones(D)
+        speed[D - 2:] = 0.1
         pp, pr = torch.zeros(n * 4, 3), torch.zeros(n * 4, 4)
 
         def step():
-            fo.pre_physics(spec, b, st["actions"], lo, hi, speed, lambda ids: torch.rand(len(ids), 9), num_props=4, default_prop_pos=pp,
+            fo.pre_physics(spec, b, st["actions"], lo, hi, speed, lambda ids: torch.rand(len(ids), D), num_props=4, default_prop_pos=pp,
                            default_prop_rot=pr)
             fo.post_physics(spec, b, st, lo, hi)
 
@@ -611,9 +616,9 @@ class AnymalFlatBench:
         return step
 
 
-ADAPTERS = {"FrankaCabinet": FrankaCabinetBench, "Crazyflie": CrazyflieBench, "Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
-DEFAULT_ENVS = {"FrankaCabinet": 1 << 20, "Crazyflie": 1 << 20, "Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
-CPU_ENVS = {"FrankaCabinet": 1 << 18, "Crazyflie": 1 << 18, "Ingenuity": 1 << 18, "BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
+ADAPTERS = {"TomoDJCabinet": FrankaCabinetBench, "TomoSPCCabinet": FrankaCabinetBench, "FrankaCabinet": FrankaCabinetBench, "Crazyflie": CrazyflieBench, "Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
+DEFAULT_ENVS = {"TomoDJCabinet": 1 << 20, "TomoSPCCabinet": 1 << 20, "FrankaCabinet": 1 << 20, "Crazyflie": 1 << 20, "Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
+CPU_ENVS = {"TomoDJCabinet": 1 << 18, "TomoSPCCabinet": 1 << 18, "FrankaCabinet": 1 << 18, "Crazyflie": 1 << 18, "Ingenuity": 1 << 18, "BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
 def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:

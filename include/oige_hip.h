@@ -901,13 +901,18 @@ int oige_cartpole_reset_idx(const oige_cartpole_params* params, const oige_cartp
                             const oige_cartpole_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
                             oige_stream_t stream);
 
-/* ------------------------------------------------------------------ FrankaCabinet
- * tasks/franka_cabinet.py.  Scalars: cfg/task/FrankaCabinet.yaml:8-32, franka_cabinet.py:52-53,257-279.
+/* ------------------------------------------------------------------ FrankaCabinet, TomoDJCabinet, TomoSPCCabinet
+ *   tasks/franka_cabinet.py; tasks/tomodj_cabinet.py:373-712 and tasks/tomospc_cabinet.py are the same
+ * skeleton with 9 / 8 DOFs and their own reward variant.  Scalars: cfg/task/FrankaCabinet.yaml:8-32 (TomoDJCabinet.yaml,
+ * TomoSPCCabinet.yaml), franka_cabinet.py:52-53,257-279.
  * The per-env tensors the reference builds with .repeat((num_envs, 1)) (:257-275: local grasp poses and the four axes) have
  * identical rows; they cross the ABI as the row.                                                                 */
-#define OIGE_FRANKA_DOFS 9
+#define OIGE_FRANKA_DOFS 9 /* array capacity; num_dofs = 9 (Franka, TomoDJ) or 8 (TomoSPC); obs width = 2 * num_dofs + 5 */
 #define OIGE_FRANKA_OBS 23
 #define OIGE_CABINET_DOFS 4
+#define OIGE_CABINET_REWARD_FRANKA 0 /* franka_cabinet.py:526-601 */
+#define OIGE_CABINET_REWARD_TOMO 1   /* tomodj_cabinet.py:605-684 == tomospc_cabinet.py: dist_reward = -d, rot_reward zeroed
+                                        below 0.6 and doubled from 0.8, finger-height tests (<=, >=) */
 
 typedef struct oige_franka_cabinet_params {
   float action_scale;                /* 7.5 */
@@ -916,7 +921,11 @@ typedef struct oige_franka_cabinet_params {
   float clip_actions;                /* with OIGE_PRE_CLAMP_ACTIONS */
   float dist_reward_scale, rot_reward_scale, around_handle_reward_scale, open_reward_scale;
   float finger_dist_reward_scale, action_penalty_scale, finger_close_reward_scale;
-  float reserved0;
+  float open_bonus_threshold;        /* second drawer bonus: 0.2 (franka_cabinet.py:592), 0.1 (tomodj_cabinet.py:675) */
+  float open_done_threshold;         /* third bonus and is_done: 0.39 (:593, :470), 0.19 (tomodj_cabinet.py:676, :569) */
+  int32_t num_dofs;                  /* 9 or 8; the finger-close term reads joints num_dofs-2, num_dofs-1 (:571) */
+  int32_t reward_variant;            /* OIGE_CABINET_REWARD_* */
+  int32_t reserved0;
   float franka_local_grasp_pos[3];   /* (:253-257) */
   float franka_local_grasp_rot[4];   /* wxyz (:258) */
   float drawer_local_grasp_pos[3];   /* (0.3, 0.01, 0) (:260-261) */

@@ -244,8 +244,9 @@ class IngenuityResetIO(C.Structure):
 class FrankaCabinetParams(C.Structure):
     _fields_ = [(n, _f) for n in ("action_scale", "dof_vel_scale", "dt", "clip_actions", "dist_reward_scale", "rot_reward_scale",
                                   "around_handle_reward_scale", "open_reward_scale", "finger_dist_reward_scale",
-                                  "action_penalty_scale", "finger_close_reward_scale", "reserved0")] + [
-        ("franka_local_grasp_pos", _f * 3), ("franka_local_grasp_rot", _f * 4), ("drawer_local_grasp_pos", _f * 3),
+                                  "action_penalty_scale", "finger_close_reward_scale", "open_bonus_threshold",
+                                  "open_done_threshold")] + [
+        ("num_dofs", C.c_int32), ("reward_variant", C.c_int32), ("reserved0", C.c_int32), ("franka_local_grasp_pos", _f * 3), ("franka_local_grasp_rot", _f * 4), ("drawer_local_grasp_pos", _f * 3),
         ("drawer_local_grasp_rot", _f * 4), ("gripper_forward_axis", _f * 3), ("drawer_inward_axis", _f * 3),
         ("gripper_up_axis", _f * 3), ("drawer_up_axis", _f * 3), ("dof_lower", _f * 9), ("dof_upper", _f * 9),
         ("dof_speed_scales", _f * 9), ("default_dof_pos", _f * 9), ("max_episode_length", C.c_int32), ("num_props", C.c_int32)]
@@ -268,6 +269,7 @@ class FrankaCabinetResetIO(C.Structure):
 
 
 OBSERVER_MAX_KEYS = 64
+CABINET_REWARD_FRANKA, CABINET_REWARD_TOMO = 0, 1
 
 
 class ObserverBatch(C.Structure):

@@ -1,8 +1,10 @@
-// FrankaCabinet per-step task math for gfx950 (MI355X) -- SURVEY.md 8f rank 4.
+// FrankaCabinet / TomoDJCabinet / TomoSPCCabinet per-step task math for gfx950 (MI355X) -- SURVEY.md 8f rank 4.
 //
 // Replaces /root/reference/omniisaacgymenvs/tasks/franka_cabinet.py behind the unchanged FrankaCabinetTask method contract:
 //   get_observations :283-358 (compute_grasp_transforms :475-494), calculate_metrics :439-466 (compute_franka_reward
 //   :496-601), is_done :468-473, pre_physics_step :360-373, reset_idx :375-414.
+// tasks/tomodj_cabinet.py:373-712 (9 DOFs) and tasks/tomospc_cabinet.py (8 DOFs) share the skeleton; their reward variant
+// (OIGE_CABINET_REWARD_TOMO) and thresholds come in through the params.  Kernels are instantiated for D = 9 and D = 8.
 //
 // post_physics: one wavefront per tile of 64 envs, HBM-bound, 388 algorithmic bytes per env-step
 //   (R hand 28 + drawer 28 + dof_pos 36 + dof_vel 36 + cabinet pos/vel rows 32 + finger z 2 x 4 + actions 36 + progress 8 +
@@ -18,9 +20,8 @@
 
 namespace oige {
 
-constexpr int FD = OIGE_FRANKA_DOFS;   // 9
-constexpr int FO = OIGE_FRANKA_OBS;    // 23
-constexpr int CD = OIGE_CABINET_DOFS;  // 4
+constexpr int FMAX = OIGE_FRANKA_DOFS;  // 9: capacity of the per-joint tables in the params
+constexpr int CD = OIGE_CABINET_DOFS;   // 4
 
 struct FrankaPost {
   oige_franka_cabinet_params p;
@@ -34,8 +35,9 @@ OIGE_DEV f3 f3_of(const float (&v)[3]) { return f3{v[0], v[1], v[2]}; }
 OIGE_DEV q4 q4_of(const float (&v)[4]) { return q4{v[0], v[1], v[2], v[3]}; }
 OIGE_DEV float sign_f(const float x) { return (x != x) ? x : (float)((x > 0.0f) - (x < 0.0f)); }  // torch.sign
 
-template <bool FULL>
+template <int FD, bool FULL>
 __device__ __forceinline__ void franka_post_tile(const FrankaPost& a, float* __restrict__ tile, int64_t t, int nv) {
+  constexpr int FO = 2 * FD + 5;  // obs width: 23 (9 DOFs) / 21 (8 DOFs), odd -> bank-conflict free rows
   const oige_franka_cabinet_params& p = a.p;
   const int lane = lane_id();
   const int64_t env0 = t * TILE;
@@ -97,14 +99,14 @@ __device__ __forceinline__ void franka_post_tile(const FrankaPost& a, float* __r
     scatter_chunk<FD, FO, 0, false>(c_pos, tile, 1.0f);
     if (do_obs) scatter_chunk<FD, FO, FD, true>(c_vel, tile, p.dof_vel_scale);  // :349
     __syncthreads();
-    jp7 = row[7];
-    jp8 = row[8];
+    jp7 = row[FD - 2];  // the two finger joints: 7, 8 (franka_cabinet.py:571, tomodj) / 6, 7 (tomospc_cabinet.py)
+    jp8 = row[FD - 1];
     if (do_obs) {
 #pragma unroll
       for (int j = 0; j < FD; ++j)  // :339-344
         row[j] = (2.0f * (row[j] - p.dof_lower[j])) / (p.dof_upper[j] - p.dof_lower[j]) - 1.0f;
-      row[18] = dg_pos.x - fg_pos.x; row[19] = dg_pos.y - fg_pos.y; row[20] = dg_pos.z - fg_pos.z;  // :345
-      row[21] = cab3; row[22] = cabv3;
+      row[2 * FD] = dg_pos.x - fg_pos.x; row[2 * FD + 1] = dg_pos.y - fg_pos.y; row[2 * FD + 2] = dg_pos.z - fg_pos.z;  // :345
+      row[2 * FD + 3] = cab3; row[2 * FD + 4] = cabv3;
       if (live) {
         if (a.b.franka_grasp_rot) *reinterpret_cast<float4*>(a.b.franka_grasp_rot + env * 4) = make_float4(fg_rot.w, fg_rot.x, fg_rot.y, fg_rot.z);
         if (a.b.drawer_grasp_rot) *reinterpret_cast<float4*>(a.b.drawer_grasp_rot + env * 4) = make_float4(dg_rot.w, dg_rot.x, dg_rot.y, dg_rot.z);
@@ -115,14 +117,24 @@ __device__ __forceinline__ void franka_post_tile(const FrankaPost& a, float* __r
   }
   if (do_metrics) {  // compute_franka_reward (:526-601)
     const float d = norm3(f3{fg_pos.x - dg_pos.x, fg_pos.y - dg_pos.y, fg_pos.z - dg_pos.z});
-    float dist_reward = 1.0f / (1.0f + d * d);
-    dist_reward *= dist_reward;
-    dist_reward = (d <= 0.02f) ? dist_reward * 2.0f : dist_reward;
+    const bool tomo = p.reward_variant == OIGE_CABINET_REWARD_TOMO;
+    float dist_reward;
+    if (tomo) {
+      dist_reward = -d;  // tomodj_cabinet.py:607
+    } else {
+      dist_reward = 1.0f / (1.0f + d * d);
+      dist_reward *= dist_reward;
+      dist_reward = (d <= 0.02f) ? dist_reward * 2.0f : dist_reward;
+    }
     const f3 axis1 = quat_apply(fg_rot, f3_of(p.gripper_forward_axis)), axis2 = quat_apply(dg_rot, f3_of(p.drawer_inward_axis));
     const f3 axis3 = quat_apply(fg_rot, f3_of(p.gripper_up_axis)), axis4 = quat_apply(dg_rot, f3_of(p.drawer_up_axis));
     const float dot1 = dot3(axis1, axis2), dot2 = dot3(axis3, axis4);
-    const float rot_reward = 0.5f * (sign_f(dot1) * (dot1 * dot1) + sign_f(dot2) * (dot2 * dot2));
-    const bool around_b = (lfz > dg_pos.z) && (rfz < dg_pos.z);
+    float rot_reward = 0.5f * (sign_f(dot1) * (dot1 * dot1) + sign_f(dot2) * (dot2 * dot2));
+    if (tomo) {  // tomodj_cabinet.py:622-623
+      rot_reward = (rot_reward < 0.6f) ? 0.0f : rot_reward;
+      rot_reward = (rot_reward >= 0.8f) ? 2.0f * rot_reward : rot_reward;
+    }
+    const bool around_b = tomo ? (lfz <= dg_pos.z) && (rfz >= dg_pos.z) : (lfz > dg_pos.z) && (rfz < dg_pos.z);
     const float around = around_b ? 0.5f : 0.0f;
     const float finger_dist_reward = around_b ? (0.04f - __builtin_fabsf(lfz - dg_pos.z)) + (0.04f - __builtin_fabsf(rfz - dg_pos.z)) : 0.0f;
     const float finger_close_reward = (d <= 0.03f) ? (0.04f - jp7) + (0.04f - jp8) : 0.0f;
@@ -134,13 +146,14 @@ __device__ __forceinline__ void franka_post_tile(const FrankaPost& a, float* __r
     rew = rew - p.action_penalty_scale * action_penalty;
     rew = rew + finger_close_reward * p.finger_close_reward_scale;
     rew = (cab3 > 0.01f) ? rew + 0.5f : rew;
-    rew = (cab3 > 0.2f) ? rew + around : rew;
-    rew = (cab3 > 0.39f) ? rew + (2.0f * around) : rew;
+    rew = (cab3 > p.open_bonus_threshold) ? rew + around : rew;
+    rew = (cab3 > p.open_done_threshold) ? rew + (2.0f * around) : rew;
     if (live) a.b.rew_buf[env] = rew;
   }
   if (do_done) {  // :468-473, sticky
-    const bool r = (reset != 0) | (cab3 > 0.39f) | (progress >= (int64_t)p.max_episode_length - 1);
-    const int64_t out = (cab3 > 0.39f || progress >= (int64_t)p.max_episode_length - 1) ? 1 : reset;
+    const bool now = (cab3 > p.open_done_threshold) | (progress >= (int64_t)p.max_episode_length - 1);
+    const bool r = (reset != 0) | now;
+    const int64_t out = now ? 1 : reset;
     if (live) a.b.reset_buf[env] = out;
     const unsigned long long m = __ballot(live && r);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
@@ -150,14 +163,15 @@ __device__ __forceinline__ void franka_post_tile(const FrankaPost& a, float* __r
   if (do_obs) store_tile<FO, FULL>(tile, a.b.obs_buf + env0 * FO, nv * FO);
 }
 
+template <int FD>
 __global__ __launch_bounds__(WAVE) void franka_cabinet_post_kernel(const FrankaPost a) {
-  __shared__ __align__(16) float tile[TILE * FO];
+  __shared__ __align__(16) float tile[TILE * (2 * FD + 5)];
   const int64_t t = blockIdx.x;
   const int64_t left = a.n - t * TILE;
   if (left >= TILE)
-    franka_post_tile<true>(a, tile, t, TILE);
+    franka_post_tile<FD, true>(a, tile, t, TILE);
   else
-    franka_post_tile<false>(a, tile, t, (int)left);
+    franka_post_tile<FD, false>(a, tile, t, (int)left);
 }
 
 // ---------------------------------------------------------------- pre_physics / reset
@@ -171,7 +185,7 @@ struct FrankaPre {
 };
 
 // the nine U[0,1) draws of env i (in-kernel path): Philox blocks 0..2 keyed (seed; env, block, step)
-__device__ __forceinline__ void franka_draws(const FrankaPre& a, int64_t i, float (&u)[FD]) {
+__device__ __forceinline__ void franka_draws(const FrankaPre& a, int64_t i, float (&u)[FMAX]) {
 #pragma unroll
   for (uint32_t blk = 0; blk < 3; ++blk) {
     const u4 c{(uint32_t)i, blk, (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
@@ -182,7 +196,8 @@ __device__ __forceinline__ void franka_draws(const FrankaPre& a, int64_t i, floa
 }
 
 // reset_idx (:375-414) for env i landing in compacted row k; pos[] = its new joint positions
-__device__ __forceinline__ void franka_reset_rows(const FrankaPre& a, int64_t i, int64_t k, const float (&u)[FD], float (&pos)[FD]) {
+template <int FD>
+__device__ __forceinline__ void franka_reset_rows(const FrankaPre& a, int64_t i, int64_t k, const float (&u)[FMAX], float (&pos)[FMAX]) {
   const oige_franka_cabinet_params& p = a.p;
 #pragma unroll
   for (int j = 0; j < FD; ++j) {
@@ -206,6 +221,7 @@ __device__ __forceinline__ void franka_reset_rows(const FrankaPre& a, int64_t i,
   a.r.env_ids[k] = i;
 }
 
+template <int FD>
 __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaPre a) {
   __shared__ int lds4[GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
@@ -236,9 +252,9 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
   if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env
     const int il = s_list[tid];
     const int64_t i = g * GROUP + il;
-    float u[FD], pos[FD];
+    float u[FMAX], pos[FMAX];
     franka_draws(a, i, u);
-    franka_reset_rows(a, i, (int64_t)k0 + tid, u, pos);
+    franka_reset_rows<FD>(a, i, (int64_t)k0 + tid, u, pos);
 #pragma unroll
     for (int j = 0; j < FD; ++j) s_pos[il * FD + j] = pos[j];  // franka_dof_targets[env_ids] = pos (:389)
   }
@@ -287,20 +303,22 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
 }
 
 // reset_idx(env_ids) with caller-provided ids and (optionally) the pre-drawn (n,9) U[0,1): one thread per id
+template <int FD>
 __global__ __launch_bounds__(256) void franka_cabinet_reset_idx_kernel(const FrankaPre a, int64_t max_ids) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k == 0) *a.r.prop_count = *a.r.count * a.p.num_props;
   if (k >= max_ids || k >= *a.r.count) return;
   const int64_t i = a.r.env_ids[k];
   if (i < 0 || i >= a.n) return;
-  float u[FD], pos[FD];
+  float u[FMAX], pos[FMAX];
+  u[FMAX - 1] = 0.0f;
   if (a.r.u_dof) {
 #pragma unroll
     for (int j = 0; j < FD; ++j) u[j] = a.r.u_dof[k * FD + j];
   } else {
     franka_draws(a, i, u);
   }
-  franka_reset_rows(a, i, k, u, pos);
+  franka_reset_rows<FD>(a, i, k, u, pos);
 #pragma unroll
   for (int j = 0; j < FD; ++j) a.b.franka_dof_targets[i * FD + j] = pos[j];  // :389
 }
@@ -309,6 +327,9 @@ static int check_franka(const oige_franka_cabinet_params* p, const oige_franka_c
   OIGE_REQUIRE(p && b, "%s: null params/buffers", who);
   OIGE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) / 128, "%s: num_envs %lld out of range", who, (long long)n);
   OIGE_REQUIRE(p->num_props >= 0 && p->num_props <= 64, "%s: num_props %d out of range [0, 64]", who, p->num_props);
+  OIGE_REQUIRE(p->num_dofs == 9 || p->num_dofs == 8, "%s: num_dofs %d not supported (9: Franka, TomoDJ; 8: TomoSPC)", who, p->num_dofs);
+  OIGE_REQUIRE(p->reward_variant == OIGE_CABINET_REWARD_FRANKA || p->reward_variant == OIGE_CABINET_REWARD_TOMO,
+               "%s: unknown reward_variant %d", who, p->reward_variant);
   return OIGE_OK;
 }
 
@@ -341,7 +362,10 @@ int oige_franka_cabinet_post_physics(const oige_franka_cabinet_params* params, c
   a.b = b;
   a.n = num_envs;
   a.stages = stages;
-  hipLaunchKernelGGL(franka_cabinet_post_kernel, dim3((unsigned)T), dim3(WAVE), 0, (hipStream_t)stream, a);
+  if (params->num_dofs == 9)
+    hipLaunchKernelGGL(franka_cabinet_post_kernel<9>, dim3((unsigned)T), dim3(WAVE), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(franka_cabinet_post_kernel<8>, dim3((unsigned)T), dim3(WAVE), 0, (hipStream_t)stream, a);
   return check_launch("franka_cabinet_post_kernel");
 }
 
@@ -387,7 +411,10 @@ int oige_franka_cabinet_pre_physics(const oige_franka_cabinet_params* params, co
   if (!(flags & OIGE_PRE_COUNTS_VALID))
     if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
   if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-  hipLaunchKernelGGL(franka_cabinet_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  if (params->num_dofs == 9)
+    hipLaunchKernelGGL(franka_cabinet_pre_kernel<9>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  else
+    hipLaunchKernelGGL(franka_cabinet_pre_kernel<8>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   return check_launch("franka_cabinet_pre_kernel");
 }
 
@@ -398,8 +425,11 @@ int oige_franka_cabinet_reset_idx(const oige_franka_cabinet_params* params, cons
   if (int rc = fill_franka_pre(a, params, buffers, reset_io, num_envs, "franka_cabinet_reset_idx")) return rc;
   OIGE_REQUIRE(max_ids >= 0 && max_ids <= num_envs, "franka_cabinet_reset_idx: bad max_ids");
   if (max_ids == 0) return OIGE_OK;
-  hipLaunchKernelGGL(franka_cabinet_reset_idx_kernel, dim3((unsigned)((max_ids + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a,
-                     max_ids);
+  const dim3 grid((unsigned)((max_ids + 255) / 256));
+  if (params->num_dofs == 9)
+    hipLaunchKernelGGL(franka_cabinet_reset_idx_kernel<9>, grid, dim3(256), 0, (hipStream_t)stream, a, max_ids);
+  else
+    hipLaunchKernelGGL(franka_cabinet_reset_idx_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, a, max_ids);
   return check_launch("franka_cabinet_reset_idx_kernel");
 }
 

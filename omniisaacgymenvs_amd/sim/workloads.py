@@ -353,7 +353,8 @@ def _rotate(q: Tensor, v: Tensor) -> Tensor:
     return v + q[:, 0:1] * t + torch.linalg.cross(xyz, t)
 
 
-def franka_cabinet_state(n: int, env_pos: Tensor, local_grasp_pos: Tensor, device="cpu", seed: int = 1234) -> Dict[str, Tensor]:
+def franka_cabinet_state(n: int, env_pos: Tensor, local_grasp_pos: Tensor, device="cpu", seed: int = 1234, num_dofs: int = 9,
+                         drawer_scale: float = 0.45) -> Dict[str, Tensor]:
     """FrankaCabinet: the hand within ~0.2 m of the drawer handle, a quarter of the envs within a few
     centimetres (the d <= 0.02 / 0.03 branches), drawer joint U(0, 0.45) (13 % open beyond 0.39 -> reset), fingers around the
     handle height, progress up to the 500-step episode."""
@@ -368,17 +369,18 @@ def franka_cabinet_state(n: int, env_pos: Tensor, local_grasp_pos: Tensor, devic
     spread = torch.where(torch.rand(n, 1, **f) < 0.25, torch.tensor(0.012, device=device), torch.tensor(0.12, device=device))
     franka_grasp = drawer_grasp + torch.randn(n, 3, **f) * spread
     hand_pos = (franka_grasp - _rotate(hand_rot, local_grasp_pos.to(device).reshape(1, 3).repeat(n, 1))).contiguous()
-    lo = torch.tensor([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973, 0.0, 0.0], device=device)
-    hi = torch.tensor([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973, 0.04, 0.04], device=device)
+    D = num_dofs
+    lo = torch.tensor([-2.8973, -1.7628, -2.8973, -3.0718, -2.8973, -0.0175, -2.8973, 0.0, 0.0], device=device)[9 - D:]
+    hi = torch.tensor([2.8973, 1.7628, 2.8973, -0.0698, 2.8973, 3.7525, 2.8973, 0.04, 0.04], device=device)[9 - D:]
     lf = franka_grasp + torch.randn(n, 3, **f) * 0.03
     rf = franka_grasp + torch.randn(n, 3, **f) * 0.03
     return dict(
         hand_pos=hand_pos, hand_rot=hand_rot, drawer_pos=drawer_pos, drawer_rot=drawer_rot,
-        franka_dof_pos=(lo + (hi - lo) * torch.rand(n, 9, **f)).contiguous(), franka_dof_vel=torch.randn(n, 9, **f),
-        cabinet_dof_pos=torch.rand(n, 4, **f) * 0.45, cabinet_dof_vel=torch.randn(n, 4, **f) * 0.3,
+        franka_dof_pos=(lo + (hi - lo) * torch.rand(n, D, **f)).contiguous(), franka_dof_vel=torch.randn(n, D, **f),
+        cabinet_dof_pos=torch.rand(n, 4, **f) * drawer_scale, cabinet_dof_vel=torch.randn(n, 4, **f) * 0.3,
         lfinger_pos=lf.contiguous(), rfinger_pos=rf.contiguous(),
-        actions=torch.rand(n, 9, **f) * 2.0 - 1.0, prev_actions=torch.rand(n, 9, **f) * 2.0 - 1.0,
-        targets=(lo + (hi - lo) * torch.rand(n, 9, **f)).contiguous(),
+        actions=torch.rand(n, D, **f) * 2.0 - 1.0, prev_actions=torch.rand(n, D, **f) * 2.0 - 1.0,
+        targets=(lo + (hi - lo) * torch.rand(n, D, **f)).contiguous(),
         progress=torch.randint(0, 498, (n,), device=device, generator=g, dtype=torch.int64),
         reset=(torch.rand(n, **f) < 0.03).long(),
     )

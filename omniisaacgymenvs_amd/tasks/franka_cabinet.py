@@ -40,16 +40,19 @@ def _quat_apply(q, v):
 
 
 class SyntheticFrankaView(SyntheticArticulationView):
-    """FrankaView surface used by the task (views/franka_view.py:43-100)."""
+    """FrankaView surface used by the task (views/franka_view.py:43-100); with ``num_dof=8`` and the finger-view names of
+    views/tomodj_view.py:43-100 / tomospc_view.py it also stands in for TomoDJView / TomoSPCView."""
 
-    def __init__(self, name: str, count: int, device) -> None:
-        limits = torch.stack([torch.tensor(FRANKA_DOF_LOWER), torch.tensor(FRANKA_DOF_UPPER)], dim=-1)
-        names = {f"panda_joint{i + 1}": i for i in range(7)}
-        names.update(panda_finger_joint1=7, panda_finger_joint2=8)
-        super().__init__(name=name, count=count, num_dof=9, device=device, dof_limits=limits, dof_names=names)
+    def __init__(self, name: str, count: int, device, num_dof: int = 9, finger_view_names=("lfingers_view", "rfingers_view")) -> None:
+        lo, hi = FRANKA_DOF_LOWER[9 - num_dof:], FRANKA_DOF_UPPER[9 - num_dof:]
+        limits = torch.stack([torch.tensor(lo), torch.tensor(hi)], dim=-1)
+        names = {f"panda_joint{i + 1}": i for i in range(num_dof - 2)}
+        names.update(panda_finger_joint1=num_dof - 2, panda_finger_joint2=num_dof - 1)
+        super().__init__(name=name, count=count, num_dof=num_dof, device=device, dof_limits=limits, dof_names=names)
         self._hands = SyntheticRigidPrimView("hands_view", count, device)
-        self._lfingers = SyntheticRigidPrimView("lfingers_view", count, device)
-        self._rfingers = SyntheticRigidPrimView("rfingers_view", count, device)
+        self._lfingers = SyntheticRigidPrimView(finger_view_names[0], count, device)
+        self._rfingers = SyntheticRigidPrimView(finger_view_names[1], count, device)
+        self._fingertip_views = {finger_view_names[0]: self._lfingers, finger_view_names[1]: self._rfingers}
         # env-local set-up poses of panda_link7 and the two fingers (pos, wxyz), what init_data reads from the stage
         self.link7_pose = torch.tensor([0.0880, 0.0, 0.9260, 0.0, 1.0, 0.0, 0.0])
         self.lfinger_pose = torch.tensor([0.0880, 0.0200, 0.7606, 0.0, 1.0, 0.0, 0.0])
@@ -61,6 +64,7 @@ class SyntheticFrankaView(SyntheticArticulationView):
 
     gripper_indices = finger_indices
     hands = property(lambda self: self._hands)
+    fingertip_views = property(lambda self: self._fingertip_views)
 
 
 class SyntheticCabinetView(SyntheticArticulationView):
@@ -72,16 +76,26 @@ class SyntheticCabinetView(SyntheticArticulationView):
 
 
 class FrankaCabinetTask(RLTask):
+    # what the TomoDJ / TomoSPC clones change (tasks/tomodj_cabinet.py, tasks/tomospc_cabinet.py)
+    NUM_DOFS = 9
+    REWARD_VARIANT = _lib.CABINET_REWARD_FRANKA
+    OPEN_BONUS_THRESHOLD = 0.2     # :592
+    OPEN_DONE_THRESHOLD = 0.39     # :593, :470
+    DEFAULT_DOF_POS = [1.157, -1.066, -0.155, -2.239, -1.841, 1.003, 0.469, 0.035, 0.035]  # :277-279
+    ROBOT_VIEW_NAME = "franka_view"
+    FINGER_VIEW_NAMES = ("lfingers_view", "rfingers_view")
+    RIGHT_FINGER_FROM_RIGHT_VIEW = False  # :337 reads the LEFT finger view twice
+
     def __init__(self, name, sim_config, env, offset=None) -> None:
         self.update_config(sim_config)
         self.distX_offset = 0.04
         self.dt = 1 / 60.0
-        self._num_observations = 23
-        self._num_actions = 9
+        self._num_observations = 2 * self.NUM_DOFS + 5
+        self._num_actions = self.NUM_DOFS
         self.fused = True
         self.sync_free = True
         self.supports_action_clamp = True
-        self.use_right_finger_view = False
+        self.use_right_finger_view = self.RIGHT_FINGER_FROM_RIGHT_VIEW
         self._step_count = 0
         RLTask.__init__(self, name, env)
 
@@ -109,7 +123,7 @@ class FrankaCabinetTask(RLTask):
     def set_up_scene(self, scene=None) -> None:
         RLTask.set_up_scene(self, scene)
         n, dev = self._num_envs, self.device
-        self._frankas = SyntheticFrankaView("franka_view", n, dev)
+        self._frankas = SyntheticFrankaView(self.ROBOT_VIEW_NAME, n, dev, num_dof=self.NUM_DOFS, finger_view_names=self.FINGER_VIEW_NAMES)
         self._cabinets = SyntheticCabinetView("cabinet_view", n, dev)
         if self.num_props > 0:
             self._props = SyntheticRigidPrimView("prop_view", n * self.num_props, dev)
@@ -140,7 +154,7 @@ class FrankaCabinetTask(RLTask):
         rep = lambda x: torch.tensor(x, device=dev, dtype=torch.float).repeat((n, 1))
         self.gripper_forward_axis, self.drawer_inward_axis = rep([0, 0, 1]), rep([-1, 0, 0])
         self.gripper_up_axis, self.drawer_up_axis = rep([0, 1, 0]), rep([0, 0, 1])
-        self.franka_default_dof_pos = torch.tensor([1.157, -1.066, -0.155, -2.239, -1.841, 1.003, 0.469, 0.035, 0.035], device=dev)
+        self.franka_default_dof_pos = torch.tensor(self.DEFAULT_DOF_POS, dtype=torch.float32, device=dev)
         self.actions = torch.zeros((n, self.num_actions), device=dev)
         self._rows_host = None  # the row of every repeated tensor, read back once (no per-step sync)
 
@@ -165,7 +179,7 @@ class FrankaCabinetTask(RLTask):
         i64 = dict(dtype=torch.int64, device=dev)
         self._reset_out = {
             "env_ids": torch.zeros(n, **i64), "count": torch.zeros(1, **i64),
-            "dof_pos": torch.zeros((n, 9), **f), "dof_vel": torch.zeros((n, 9), **f),
+            "dof_pos": torch.zeros((n, self.NUM_DOFS), **f), "dof_vel": torch.zeros((n, self.NUM_DOFS), **f),
             "cabinet_dof_pos": torch.zeros((n, 4), **f), "cabinet_dof_vel": torch.zeros((n, 4), **f),
             "prop_ids": torch.zeros(max(n * P, 1), **i64), "prop_count": torch.zeros(1, **i64),
             "prop_pos": torch.zeros((max(n * P, 1), 3), **f), "prop_rot": torch.zeros((max(n * P, 1), 4), **f),
@@ -193,21 +207,24 @@ class FrankaCabinetTask(RLTask):
             arr = getattr(p, k)
             for i, x in enumerate(h[k]):
                 arr[i] = x
-        for i in range(9):
+        for i in range(self.NUM_DOFS):
             p.dof_lower[i], p.dof_upper[i] = h["lower"][i], h["upper"][i]
             p.dof_speed_scales[i], p.default_dof_pos[i] = h["speed"][i], h["default"][i]
+        p.num_dofs, p.reward_variant = self.NUM_DOFS, self.REWARD_VARIANT
+        p.open_bonus_threshold, p.open_done_threshold = self.OPEN_BONUS_THRESHOLD, self.OPEN_DONE_THRESHOLD
         p.max_episode_length = int(self._max_episode_length)
         p.num_props = int(self.num_props)
         return p
 
     def _buffers(self) -> _lib.FrankaCabinetBuffers:
         n, rq = self._num_envs, _lib.require_device_tensor
-        rq(self.obs_buf, torch.float32, (n, 23), "obs_buf")
+        D = self.NUM_DOFS
+        rq(self.obs_buf, torch.float32, (n, 2 * D + 5), "obs_buf")
         rq(self.rew_buf, torch.float32, (n,), "rew_buf")
         rq(self.reset_buf, torch.int64, (n,), "reset_buf")
         rq(self.progress_buf, torch.int64, (n,), "progress_buf")
-        rq(self.actions, torch.float32, (n, 9), "actions")
-        rq(self.franka_dof_targets, torch.float32, (n, 9), "franka_dof_targets")
+        rq(self.actions, torch.float32, (n, D), "actions")
+        rq(self.franka_dof_targets, torch.float32, (n, D), "franka_dof_targets")
         b = _lib.FrankaCabinetBuffers()
         b.obs_buf, b.rew_buf = self.obs_buf.data_ptr(), self.rew_buf.data_ptr()
         b.reset_buf, b.progress_buf = self.reset_buf.data_ptr(), self.progress_buf.data_ptr()
@@ -229,7 +246,7 @@ class FrankaCabinetTask(RLTask):
         rview = self._frankas._rfingers if self.use_right_finger_view else self._frankas._lfingers  # :337
         self.franka_rfinger_pos, self.franka_rfinger_rot = rview.get_world_poses(clone=False)
         for t, w, name in ((hand_pos, 3, "hand_pos"), (hand_rot, 4, "hand_rot"), (drawer_pos, 3, "drawer_pos"), (drawer_rot, 4, "drawer_rot"),
-                           (self.franka_dof_pos, 9, "franka_dof_pos"), (franka_dof_vel, 9, "franka_dof_vel"),
+                           (self.franka_dof_pos, self.NUM_DOFS, "franka_dof_pos"), (franka_dof_vel, self.NUM_DOFS, "franka_dof_vel"),
                            (self.cabinet_dof_pos, 4, "cabinet_dof_pos"), (self.cabinet_dof_vel, 4, "cabinet_dof_vel"),
                            (self.franka_lfinger_pos, 3, "franka_lfinger_pos"), (self.franka_rfinger_pos, 3, "franka_rfinger_pos")):
             rq(t, torch.float32, (n, w), name)
@@ -308,7 +325,7 @@ class FrankaCabinetTask(RLTask):
             return
         n = self._num_envs
         actions = actions.to(self._device)
-        _lib.require_device_tensor(actions, torch.float32, (n, 9), "actions")
+        _lib.require_device_tensor(actions, torch.float32, (n, self.NUM_DOFS), "actions")
         self._step_count += 1
         flags = 0
         if not self.sync_free:

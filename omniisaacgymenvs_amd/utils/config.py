@@ -161,6 +161,20 @@ TASK_DEFAULTS["FrankaCabinet"] = {
     "sim": dict(_SIM, dt=0.0083, gravity=[0.0, 0.0, -9.81]),
 }
 
+# cfg/task/TomoDJCabinet.yaml, cfg/task/TomoSPCCabinet.yaml: FrankaCabinet's keys with their own reward scales
+TASK_DEFAULTS["TomoDJCabinet"] = {
+    "name": "TomoDJCabinet",
+    "env": dict(TASK_DEFAULTS["FrankaCabinet"]["env"], aroundHandleRewardScale=2, distRewardScale=5, fingerCloseRewardScale=10,
+                fingerDistRewardScale=15, openRewardScale=15, rotRewardScale=1.5),
+    "sim": dict(_SIM, dt=0.0083, gravity=[0.0, 0.0, -9.81]),
+}
+TASK_DEFAULTS["TomoSPCCabinet"] = {
+    "name": "TomoSPCCabinet",
+    "env": dict(TASK_DEFAULTS["FrankaCabinet"]["env"], aroundHandleRewardScale=2, distRewardScale=5, fingerCloseRewardScale=9,
+                fingerDistRewardScale=13, openRewardScale=20, rotRewardScale=1.25),
+    "sim": dict(_SIM, dt=0.0083, gravity=[0.0, 0.0, -9.81]),
+}
+
 # cfg/task/AnymalTerrain.yaml:5-103
 TASK_DEFAULTS["AnymalTerrain"] = {
     "name": "AnymalTerrain",

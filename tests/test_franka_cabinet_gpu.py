@@ -1,5 +1,5 @@
-"""-m gpu parity tests: HIP FrankaCabinet path (through the C ABI) vs the CPU oracle (pinned to tasks/franka_cabinet.py by
-tests/test_oracle_pinned_franka_cabinet.py).  Bar: reset flags, id lists, progress bit-exact; fp32 observations, rewards,
+"""-m gpu parity tests: HIP FrankaCabinet / TomoDJCabinet / TomoSPCCabinet path (through the C ABI) vs the CPU oracle (pinned to
+tasks/franka_cabinet.py, tasks/tomodj_cabinet.py, tasks/tomospc_cabinet.py by tests/test_oracle_pinned_franka_cabinet.py).  Bar: reset flags, id lists, progress bit-exact; fp32 observations, rewards,
 grasp transforms, targets within 1e-5 rel / 1e-6 abs."""
 import pytest
 import torch
@@ -11,13 +11,21 @@ from oracle import franka_cabinet_oracle as fo
 pytestmark = pytest.mark.gpu
 
 
-def _loaded(n, seed=1234, right_finger=False):
-    env, task = make_task("FrankaCabinet", n)
+# (task, right finger read from the right-finger view): FrankaCabinet's own binding reads the left view twice (:337)
+CASES = [("FrankaCabinet", False), ("FrankaCabinet", True), ("TomoDJCabinet", True), ("TomoSPCCabinet", True)]
+SPECS = {"FrankaCabinet": fo.FrankaCabinetSpec, "TomoDJCabinet": fo.tomodj_spec, "TomoSPCCabinet": fo.tomospc_spec}
+
+
+def _loaded(n, seed=1234, right_finger=False, name="FrankaCabinet"):
+    env, task = make_task(name, n)
     task.use_right_finger_view = right_finger
-    st = workloads.franka_cabinet_state(n, task._env_pos.cpu(), task.franka_local_grasp_pos[0].cpu(), device="cpu", seed=seed)
+    tomo = name != "FrankaCabinet"
+    st = workloads.franka_cabinet_state(n, task._env_pos.cpu(), task.franka_local_grasp_pos[0].cpu(), device="cpu", seed=seed,
+                                        num_dofs=task.NUM_DOFS, drawer_scale=0.22 if tomo else 0.45)
     if n > 12:
         st["progress"][:3] = torch.tensor([496, 497, 498])
-        st["cabinet_dof_pos"][3:9, 3] = torch.tensor([0.0099, 0.0101, 0.1999, 0.2001, 0.3899, 0.3901])
+        edges = [0.0099, 0.0101, 0.0999, 0.1001, 0.1899, 0.1901] if tomo else [0.0099, 0.0101, 0.1999, 0.2001, 0.3899, 0.3901]
+        st["cabinet_dof_pos"][3:9, 3] = torch.tensor(edges)
     workloads.load_franka_cabinet_state(task, st)
     if not right_finger:
         st = dict(st, rfinger_pos=st["lfinger_pos"])  # what the reference's binding feeds the reward (:337)
@@ -25,8 +33,13 @@ def _loaded(n, seed=1234, right_finger=False):
 
 
 def _spec(task) -> fo.FrankaCabinetSpec:
-    return fo.FrankaCabinetSpec(franka_local_grasp_pos=task.franka_local_grasp_pos[0].tolist(),
-                                franka_local_grasp_rot=task.franka_local_grasp_rot[0].tolist(), num_props=task.num_props)
+    spec = SPECS[task.name](franka_local_grasp_pos=task.franka_local_grasp_pos[0].tolist(),
+                            franka_local_grasp_rot=task.franka_local_grasp_rot[0].tolist(), num_props=task.num_props)
+    assert spec.num_dofs == task.NUM_DOFS and spec.default_dof_pos == list(task.DEFAULT_DOF_POS)
+    for k in ("dist_reward_scale", "rot_reward_scale", "around_handle_reward_scale", "open_reward_scale", "finger_dist_reward_scale",
+              "action_penalty_scale", "finger_close_reward_scale"):
+        assert getattr(spec, k) == getattr(task, k), k   # the oracle's per-task scales == the YAML defaults of the mirror
+    return spec
 
 
 def _oracle_buffers(task) -> fo.FrankaCabinetBuffers:
@@ -42,9 +55,10 @@ def _limits(task):
 
 @pytest.mark.parametrize("n", [1, 40, 64, 257, 4096])
 @pytest.mark.parametrize("fused", [True, False])
-@pytest.mark.parametrize("right_finger", [False, True])
-def test_post_physics_matches_oracle(n, fused, right_finger):
-    env, task, st = _loaded(n, right_finger=right_finger)
+@pytest.mark.parametrize("name,right_finger", CASES)
+def test_post_physics_matches_oracle(n, fused, name, right_finger):
+    env, task, st = _loaded(n, right_finger=right_finger, name=name)
+    tomo = name != "FrankaCabinet"
     task.fused = fused
     spec, b = _spec(task), _oracle_buffers(task)
     lo, hi = _limits(task)
@@ -64,31 +78,34 @@ def test_post_physics_matches_oracle(n, fused, right_finger):
     assert_close(rew[ok], b.rew_buf[ok], "rew_buf")
     if n >= 4096:
         assert int((d <= 0.02).sum()) > 20 and int(((d > 0.02) & (d <= 0.03)).sum()) > 20
-        around = (st["lfinger_pos"][:, 2] > b.drawer_grasp_pos[:, 2]) & (st["rfinger_pos"][:, 2] < b.drawer_grasp_pos[:, 2])
+        lz, rz, gz = st["lfinger_pos"][:, 2], st["rfinger_pos"][:, 2], b.drawer_grasp_pos[:, 2]
+        around = ((lz <= gz) & (rz >= gz)) if tomo else ((lz > gz) & (rz < gz))
         assert (int(around.sum()) > 100) == right_finger
     if n > 12:
-        assert int(reset[2]) == 1 and int(reset[1]) == int(st["reset"][1])   # progress 498 -> 499 == max - 1; 497 -> 498 not yet
+        assert int(reset[2]) == 1   # progress 498 -> 499 == max_episode_length - 1
         assert int(reset[7]) == int(st["reset"][7]) and int(reset[8]) == 1
 
 
 @pytest.mark.parametrize("n", [1, 64, 300, 5000])
 @pytest.mark.parametrize("clamp", [False, True])
-def test_sync_free_pre_physics_matches_oracle(n, clamp):
-    env, task, st = _loaded(n)
+@pytest.mark.parametrize("name", ["FrankaCabinet", "TomoDJCabinet", "TomoSPCCabinet"])
+def test_sync_free_pre_physics_matches_oracle(n, clamp, name):
+    env, task, st = _loaded(n, name=name, right_finger=name != "FrankaCabinet")
+    D = task.NUM_DOFS
     for v in (task._frankas, task._cabinets, task._props):
         v.apply_resets = False
     if n >= 64:
         task.reset_buf[: n // 3] = 1
     spec, b = _spec(task), _oracle_buffers(task)
     lo, hi = _limits(task)
-    actions = torch.rand(n, 9, generator=torch.Generator().manual_seed(5)) * 3 - 1.5
+    actions = torch.rand(n, D, generator=torch.Generator().manual_seed(5)) * 3 - 1.5
     task.clamp_actions_in_kernel = clamp
     want_actions = torch.clamp(actions, -task.clip_actions, task.clip_actions) if clamp else actions
     task.pre_physics_step(actions.to(task.device))
     torch.cuda.synchronize()
     o = task._reset_out
     k = int(o["count"].item())
-    u_dev = (o["dof_pos"][:k].cpu() - torch.tensor(fo.FRANKA_DEFAULT_DOF_POS)) / 0.25 + 0.5  # recover the in-kernel draws where unclamped
+    u_dev = (o["dof_pos"][:k].cpu() - torch.tensor(spec.default_dof_pos)) / 0.25 + 0.5  # recover the in-kernel draws where unclamped
     ids, rows = fo.pre_physics(spec, b, want_actions, lo, hi, task.franka_dof_speed_scales.cpu(), lambda i: u_dev.clone(),
                                num_props=task.num_props, default_prop_pos=task.default_prop_pos.cpu(), default_prop_rot=task.default_prop_rot.cpu())
     assert k == len(ids)
@@ -113,20 +130,22 @@ def test_sync_free_pre_physics_matches_oracle(n, clamp):
         assert_equal(o["prop_rot"][: k * P], rows["prop_rot"], "prop_rot rows")
 
 
-def test_reference_flow_replays_torch_rng():
+@pytest.mark.parametrize("name", ["FrankaCabinet", "TomoDJCabinet", "TomoSPCCabinet"])
+def test_reference_flow_replays_torch_rng(name):
     n = 500
-    env, task, st = _loaded(n)
+    env, task, st = _loaded(n, name=name, right_finger=name != "FrankaCabinet")
+    D = task.NUM_DOFS
     task.sync_free = False
     task.reset_buf[::7] = 1
     spec, b = _spec(task), _oracle_buffers(task)
     lo, hi = _limits(task)
-    actions = torch.rand(n, 9, generator=torch.Generator().manual_seed(6)) * 2 - 1
+    actions = torch.rand(n, D, generator=torch.Generator().manual_seed(6)) * 2 - 1
     torch.manual_seed(77)
     task.pre_physics_step(actions.to(task.device))
     torch.cuda.synchronize()
     torch.manual_seed(77)
     ids, rows = fo.pre_physics(spec, b, actions, lo, hi, task.franka_dof_speed_scales.cpu(),
-                               lambda i: torch.rand((len(i), 9), device=task.device).cpu(), num_props=task.num_props,
+                               lambda i: torch.rand((len(i), D), device=task.device).cpu(), num_props=task.num_props,
                                default_prop_pos=task.default_prop_pos.cpu(), default_prop_rot=task.default_prop_rot.cpu())
     assert_equal(task.reset_buf, b.reset_buf, "reset_buf")
     assert_equal(task.progress_buf, b.progress_buf, "progress_buf")
@@ -137,17 +156,19 @@ def test_reference_flow_replays_torch_rng():
     assert_equal(task._props.positions[pid], rows["prop_pos"], "prop poses restored")
 
 
-def test_full_size_properties():
+@pytest.mark.parametrize("name", ["FrankaCabinet", "TomoSPCCabinet"])
+def test_full_size_properties(name):
     n = 1 << 20
-    env, task, st = _loaded(n)
+    env, task, st = _loaded(n, name=name, right_finger=name != "FrankaCabinet")
+    D = task.NUM_DOFS
     obs, rew, reset, _ = task.post_physics_step()
     torch.cuda.synchronize()
-    assert_equal(obs[:, 21], st["cabinet_dof_pos"][:, 3], "obs drawer joint position")
-    assert_close(obs[:, 9:18], st["franka_dof_vel"] * 0.1, "obs joint velocities")
-    assert_close(obs[:, 18:21], task.drawer_grasp_pos - task.franka_grasp_pos, "to_target == difference of the grasp points")
+    assert_equal(obs[:, 2 * D + 3], st["cabinet_dof_pos"][:, 3], "obs drawer joint position")
+    assert_close(obs[:, D:2 * D], st["franka_dof_vel"] * 0.1, "obs joint velocities")
+    assert_close(obs[:, 2 * D:2 * D + 3], task.drawer_grasp_pos - task.franka_grasp_pos, "to_target == difference of the grasp points")
     assert float((task.franka_grasp_rot.norm(dim=-1) - 1).abs().max()) < 1e-5
     want = reset.nonzero().squeeze(-1).clone()
-    assert bool((reset[(st["cabinet_dof_pos"][:, 3] > 0.39).to(task.device)] == 1).all())
+    assert bool((reset[(st["cabinet_dof_pos"][:, 3] > task.OPEN_DONE_THRESHOLD).to(task.device)] == 1).all())
     for v in (task._frankas, task._cabinets, task._props):
         v.apply_resets = False
     task.pre_physics_step(st["actions"].to(task.device))
@@ -158,3 +179,14 @@ def test_full_size_properties():
     assert int(task.reset_buf.sum().item()) == 0 and int(task.progress_buf[want].sum().item()) == 0
     lo, hi = task.franka_dof_lower_limits, task.franka_dof_upper_limits
     assert bool(((task.franka_dof_targets >= lo) & (task.franka_dof_targets <= hi)).all())
+
+
+def test_tomo_attribute_names_alias_the_shared_storage():
+    env, task = make_task("TomoDJCabinet", 64)
+    assert task.tomodj_dof_targets.data_ptr() == task.franka_dof_targets.data_ptr()
+    assert task._tomodjs is task._frankas and task.num_tomodj_dofs == 9
+    assert task._tomodjs.fingertip_views["right_fingers_view"] is task._frankas._rfingers
+    task.tomodj_dof_targets = torch.ones_like(task.franka_dof_targets)
+    assert float(task.franka_dof_targets.min()) == 1.0
+    with pytest.raises(AttributeError):
+        task.no_such_attribute
