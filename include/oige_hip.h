@@ -155,6 +155,8 @@ typedef struct oige_locomotion_reset_io {
   float* root_pos_out;           /* out (n,3) */
   float* root_rot_out;           /* out (n,4) */
   float* root_vel_out;           /* out (n,6) zeros */
+  const uint64_t* step_ptr;      /* NULL, or a device scalar read INSTEAD of `step`: a step captured into a HIP graph bakes
+                                    its by-value arguments, so the replaying caller advances this counter on the stream */
 } oige_locomotion_reset_io;
 
 #define OIGE_PRE_CLAMP_ACTIONS 1u /* fold VecEnvRLGames' torch.clamp(actions, +-clip) (vec_env_rlgames.py:77) */

@@ -53,7 +53,7 @@ class LocomotionResetIO(C.Structure):
         ("initial_root_pos", _fp), ("initial_root_rot", _fp), ("initial_dof_pos", _fp), ("u_pos", _fp), ("u_vel", _fp),
         ("seed", C.c_uint64), ("step", C.c_uint64),
         ("env_ids", _fp), ("count", _fp), ("dof_pos_out", _fp), ("dof_vel_out", _fp),
-        ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp),
+        ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp), ("step_ptr", _fp),
     ]
 
 

@@ -9,8 +9,10 @@ getters with ``clone=False`` hand out the internal buffers, setters scatter rows
 Extension for the sync-free path: every setter also accepts ``count=<device int64 scalar>``
 with full-capacity ``values``/``indices`` buffers (rows past ``count`` are undefined).  PhysX
 would consume (values, indices, count) on the device; this stand-in either applies them with a
-host read of ``count`` (``apply_resets=True``: functional tests) or drops them
-(``apply_resets=False``: benchmarking the task math alone).
+host read of ``count`` (``apply_resets=True``: functional tests), drops them
+(``apply_resets=False``: benchmarking the task math alone), or applies them on the device without
+reading ``count`` (``apply_resets="device"``: a full-capacity masked scatter, legal inside HIP graph
+capture -- what ``LocomotionTask.capture_step`` needs).
 """
 from __future__ import annotations
 
@@ -118,6 +120,17 @@ class SyntheticArticulationView:
         return indices[:n].long()
 
     def _scatter(self, buf: Tensor, values: Tensor, indices, count) -> None:
+        if count is not None and self.apply_resets == "device":
+            # rows k >= count must not land: point them at row 0's target and give them row 0's value (duplicates then write
+            # identical data), or -- when count == 0 -- at a row that is rewritten with its own current value
+            cap = indices.shape[0]
+            valid = torch.arange(cap, device=buf.device) < count
+            idx0 = indices[:1].long().clamp(0, buf.shape[0] - 1)          # (1,): indexing with a 0-d tensor would read it back
+            idx = torch.where(valid, indices.long(), idx0)
+            v0 = torch.where(count.reshape(-1)[:1] > 0, values[0], buf.index_select(0, idx0)[0])
+            vals = torch.where(valid.reshape(-1, *([1] * (values.dim() - 1))), values, v0)
+            buf.index_put_((idx,), vals)
+            return
         rows = self._rows(indices, count)
         if rows is False:
             return
