@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- fused obs+reward+reset env-steps/s (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter|BallBalance|Ingenuity|Crazyflie|FrankaCabinet|TomoDJCabinet|TomoSPCCabinet]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--envs E] [--task Ant|Humanoid|ShadowHand|AnymalTerrain|Anymal|AllegroHand|Quadcopter|BallBalance|Ingenuity|Crazyflie|FrankaCabinet|TomoDJCabinet|TomoSPCCabinet|TomoDJnewhandCabinet|TomoDJnewhandTendonCabinet|TomoSPCnewhandCabinet]
 
 One "step" = one pre_physics_step (reset-id compaction, reset of the flagged envs, action scaling /
 PD torques) + one post_physics_step (progress, obs, reward, done[, in-step reset]) over a batch of
@@ -568,6 +568,62 @@ class FrankaCabinetBench:
         return step
 
 
+class NewhandCabinetBench:
+    """the fork's five-finger cabinet tasks (10 keypoints, obs(2D+5), reward, sticky done [+ terminate])."""
+
+    def __init__(self, name, n, dev, seed):
+        from helpers import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+
+        self.env, self.task = make_task(name, n, device=dev, seed=seed)
+        t = self.task
+        st = workloads.newhand_cabinet_state(n, t._env_pos, t.robot_dof_lower_limits, t.robot_dof_upper_limits, t.num_actions, device=dev,
+                                             seed=seed)
+        workloads.load_newhand_cabinet_state(t, st)
+        for v in (t._robots, t._cabinets, t._props):
+            v.apply_resets = False
+        self.actions = st["actions"]
+        D, A, term = t.NUM_DOFS, t.num_actions, 8 if t.TERMINATE_ON_LIMITS else 0
+        self.post_bytes = (16 + 5 * 28 + 28 + 8 * D + 32 + 4 * A + 16 + term) + (4 * (2 * D + 5) + 20 + 120 + term)  # csrc/newhand_cabinet.hip
+        self.kernel = "newhand_cabinet_post_kernel"
+        self.workload = f"{name} keypoints+obs({2 * D + 5})+reward+reset fused, {n} envs per GPU, synthetic finger/drawer/DOF state"
+        self.extra_cfg = {"num_dof": D, "num_actions": A, "num_props": t.num_props}
+
+    def pre(self):
+        self.task.pre_physics_step(self.actions)
+
+    def post(self):
+        self.task.post_physics_step()
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from omniisaacgymenvs_amd.tasks import newhand_cabinet as nh
+        from oracle import newhand_cabinet_oracle as no
+
+        cls = getattr(nh, name + "Task")
+        spec = {"TomoDJnewhandCabinet": no.tomodj_newhand_spec, "TomoSPCnewhandCabinet": no.tomospc_newhand_spec,
+                "TomoDJnewhandTendonCabinet": lambda: no.tomodj_newhand_tendon_spec(cls.ACTUATED)}[name]()
+        D, A = spec.num_dofs, spec.num_actions
+        g = torch.Generator().manual_seed(D)
+        lo, hi = -(torch.rand(D, generator=g) + 0.3), torch.rand(D, generator=g) + 0.3
+        st = workloads.newhand_cabinet_state(n, torch.zeros(n, 3), lo, hi, A, device="cpu", seed=1234)
+        b = no.NewhandBuffers(torch.zeros(n, 2 * D + 5), torch.zeros(n), st["reset"].clone(), st["progress"].clone(), st["prev_actions"].clone(),
+                              st["targets"].clone(), torch.zeros(n, 5, 3), torch.zeros(n, 5, 3), st["terminate"].clone())
+        speed = torch.ones(D)
+        speed[D - 19:] = 5
+        pp, pr = torch.zeros(n * 4, 3), torch.zeros(n * 4, 4)
+
+        def step():
+            no.pre_physics(spec, b, st["actions"], lo, hi, speed, lambda ids: torch.rand(len(ids), D), default_prop_pos=pp, default_prop_rot=pr)
+            no.post_physics(spec, b, st, lo, hi)
+
+        return step
+
+
 class AnymalFlatBench:
     """Anymal on flat ground (obs 48, 6-term reward, non-sticky done, position targets)."""
 
@@ -616,9 +672,9 @@ class AnymalFlatBench:
         return step
 
 
-ADAPTERS = {"TomoDJCabinet": FrankaCabinetBench, "TomoSPCCabinet": FrankaCabinetBench, "FrankaCabinet": FrankaCabinetBench, "Crazyflie": CrazyflieBench, "Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
-DEFAULT_ENVS = {"TomoDJCabinet": 1 << 20, "TomoSPCCabinet": 1 << 20, "FrankaCabinet": 1 << 20, "Crazyflie": 1 << 20, "Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
-CPU_ENVS = {"TomoDJCabinet": 1 << 18, "TomoSPCCabinet": 1 << 18, "FrankaCabinet": 1 << 18, "Crazyflie": 1 << 18, "Ingenuity": 1 << 18, "BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
+ADAPTERS = {"TomoDJnewhandCabinet": NewhandCabinetBench, "TomoDJnewhandTendonCabinet": NewhandCabinetBench, "TomoSPCnewhandCabinet": NewhandCabinetBench, "TomoDJCabinet": FrankaCabinetBench, "TomoSPCCabinet": FrankaCabinetBench, "FrankaCabinet": FrankaCabinetBench, "Crazyflie": CrazyflieBench, "Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
+DEFAULT_ENVS = {"TomoDJnewhandCabinet": 1 << 19, "TomoDJnewhandTendonCabinet": 1 << 19, "TomoSPCnewhandCabinet": 1 << 19, "TomoDJCabinet": 1 << 20, "TomoSPCCabinet": 1 << 20, "FrankaCabinet": 1 << 20, "Crazyflie": 1 << 20, "Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
+CPU_ENVS = {"TomoDJnewhandCabinet": 1 << 17, "TomoDJnewhandTendonCabinet": 1 << 17, "TomoSPCnewhandCabinet": 1 << 17, "TomoDJCabinet": 1 << 18, "TomoSPCCabinet": 1 << 18, "FrankaCabinet": 1 << 18, "Crazyflie": 1 << 18, "Ingenuity": 1 << 18, "BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
 def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:

@@ -1007,6 +1007,74 @@ int oige_franka_cabinet_reset_idx(const oige_franka_cabinet_params* params, cons
                                   const oige_franka_cabinet_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
                                   oige_stream_t stream);
 
+/* ------------------------------------------------------------------ TomoDJnewhandCabinet, TomoDJnewhandTendonCabinet,
+ * TomoSPCnewhandCabinet: the fork's five-finger cabinet tasks, tasks/tomodj_newhand_cabinet.py (26 DOFs),
+ * tasks/tomodj_newhandTendon_cabinet.py (26 DOFs, 22 actuated) and tasks/tomospc_newhand_cabinet.py (25 DOFs).  Line numbers
+ * below are tomodj_newhand_cabinet.py's.  Per-env tensors with identical rows cross the ABI as the row.              */
+#define OIGE_NEWHAND_MAX_DOFS 26
+#define OIGE_NEWHAND_KEYPOINTS 5
+
+typedef struct oige_newhand_cabinet_params {
+  float action_scale, dof_vel_scale, dt, clip_actions;
+  float dist_reward_scale, rot_reward_scale, around_handle_reward_scale, open_reward_scale, action_penalty_scale;
+  float around_lower;                 /* 0.2732: every fingertip keypoint's x offset from the drawer must exceed it ... */
+  float around_upper;                 /* ... and stay below 0.3149 (TomoSPC: 0.3154) */
+  float reserved0;
+  int32_t num_dofs;                   /* 26 or 25; obs width = 2 * num_dofs + 5 */
+  int32_t num_actions;                /* 26, 25, or 22 (Tendon: the actuated joints) */
+  int32_t rot_reward_thresholds;      /* TomoSPC: rot_reward zeroed below 0.6, doubled from 0.8 */
+  int32_t terminate_on_limits;        /* Tendon: terminate_buf = any scaled joint position outside +-1.05; -100 reward */
+  int32_t max_episode_length;         /* 500 */
+  int32_t num_props;
+  float drawer_local_keypoint_offsets[OIGE_NEWHAND_KEYPOINTS][3]; /* post_reset */
+  float local_thumb_pose_pos[3];              /* (0.038, 0.008, 0) */
+  float local_another_finger_pose_pos[3];     /* (0.024, -0.002, 0) */
+  float left_hand_forward_axis[3], drawer_inward_axis[3], left_hand_up_axis[3], drawer_up_axis[3];
+  float dof_lower[OIGE_NEWHAND_MAX_DOFS], dof_upper[OIGE_NEWHAND_MAX_DOFS];
+  float dof_speed_scales[OIGE_NEWHAND_MAX_DOFS];  /* 1, finger joints 5 */
+  float default_dof_pos[OIGE_NEWHAND_MAX_DOFS];
+  int32_t actuated_dof_indices[OIGE_NEWHAND_MAX_DOFS]; /* first num_actions entries: action column -> joint */
+} oige_newhand_cabinet_params;
+
+typedef struct oige_newhand_cabinet_state {  /* view getters of get_observations, read-only */
+  const float* hand_rot;                           /* (N,4) left hand */
+  const float* finger_pos[OIGE_NEWHAND_KEYPOINTS]; /* (N,3) each: thumb, fore, middle, ring, little */
+  const float* finger_rot[OIGE_NEWHAND_KEYPOINTS]; /* (N,4) each */
+  const float* drawer_pos;                         /* (N,3) */
+  const float* drawer_rot;                         /* (N,4) */
+  const float* dof_pos;                            /* (N,D) */
+  const float* dof_vel;                            /* (N,D) */
+  const float* cabinet_dof_pos;                    /* (N,4): column 3 = drawer_top_joint */
+  const float* cabinet_dof_vel;                    /* (N,4) */
+} oige_newhand_cabinet_state;
+
+typedef struct oige_newhand_cabinet_buffers {
+  float* obs_buf;            /* (N, 2D+5) */
+  float* rew_buf;            /* (N,) */
+  int64_t* reset_buf;        /* (N,) sticky */
+  int64_t* progress_buf;     /* (N,) */
+  float* actions;            /* (N,A) */
+  float* dof_targets;        /* (N,D) */
+  float* keypoints_finger;   /* (N,5,3) or NULL: task attributes written by the obs stage */
+  float* keypoints_drawer;   /* (N,5,3) or NULL */
+  int64_t* terminate_buf;    /* (N,) with terminate_on_limits: read by the reward (the PREVIOUS is_done's flags), rewritten by is_done */
+  int32_t* reset_workspace;  /* as oige_locomotion_buffers.reset_workspace */
+} oige_newhand_cabinet_buffers;
+
+/* post_physics_step: progress += 1, get_observations, calculate_metrics (compute_*_reward), is_done.  `stages` as for locomotion. */
+int oige_newhand_cabinet_post_physics(const oige_newhand_cabinet_params* params, const oige_newhand_cabinet_state* state,
+                                      const oige_newhand_cabinet_buffers* buffers, int64_t num_envs, uint32_t stages,
+                                      oige_stream_t stream);
+
+/* reset rows: same layout as oige_franka_cabinet_reset_io with D = num_dofs columns; u_dof is (n,D).               */
+int oige_newhand_cabinet_pre_physics(const oige_newhand_cabinet_params* params, const float* actions_in,
+                                     const oige_newhand_cabinet_buffers* buffers,
+                                     const oige_franka_cabinet_reset_io* reset_io, int64_t num_envs, uint32_t flags,
+                                     oige_stream_t stream);
+int oige_newhand_cabinet_reset_idx(const oige_newhand_cabinet_params* params, const oige_newhand_cabinet_buffers* buffers,
+                                   const oige_franka_cabinet_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                                   oige_stream_t stream);
+
 /* ------------------------------------------------------------------ Episode-stat observer
  * utils/rlgames/rlgames_utils.py:52-85 (RLGPUAlgoObserver.process_infos / after_print_stats).                     */
 #define OIGE_OBSERVER_MAX_KEYS 64

@@ -268,6 +268,28 @@ class FrankaCabinetResetIO(C.Structure):
                            "prop_count", "prop_pos_out", "prop_rot_out")]
 
 
+class NewhandCabinetParams(C.Structure):
+    _fields_ = [(n, _f) for n in ("action_scale", "dof_vel_scale", "dt", "clip_actions", "dist_reward_scale", "rot_reward_scale",
+                                  "around_handle_reward_scale", "open_reward_scale", "action_penalty_scale", "around_lower",
+                                  "around_upper", "reserved0")] + [
+        (n, C.c_int32) for n in ("num_dofs", "num_actions", "rot_reward_thresholds", "terminate_on_limits", "max_episode_length",
+                                 "num_props")] + [
+        ("drawer_local_keypoint_offsets", (_f * 3) * 5), ("local_thumb_pose_pos", _f * 3), ("local_another_finger_pose_pos", _f * 3),
+        ("left_hand_forward_axis", _f * 3), ("drawer_inward_axis", _f * 3), ("left_hand_up_axis", _f * 3), ("drawer_up_axis", _f * 3),
+        ("dof_lower", _f * 26), ("dof_upper", _f * 26), ("dof_speed_scales", _f * 26), ("default_dof_pos", _f * 26),
+        ("actuated_dof_indices", C.c_int32 * 26)]
+
+
+class NewhandCabinetState(C.Structure):
+    _fields_ = [("hand_rot", _fp), ("finger_pos", _fp * 5), ("finger_rot", _fp * 5)] + [
+        (n, _fp) for n in ("drawer_pos", "drawer_rot", "dof_pos", "dof_vel", "cabinet_dof_pos", "cabinet_dof_vel")]
+
+
+class NewhandCabinetBuffers(C.Structure):
+    _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "actions", "dof_targets", "keypoints_finger",
+                                   "keypoints_drawer", "terminate_buf", "reset_workspace")]
+
+
 OBSERVER_MAX_KEYS = 64
 CABINET_REWARD_FRANKA, CABINET_REWARD_TOMO = 0, 1
 
@@ -388,6 +410,12 @@ SIGNATURES = {
                                                   C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_uint32, _P]),
     "oige_franka_cabinet_reset_idx": (C.c_int, [C.POINTER(FrankaCabinetParams), C.POINTER(FrankaCabinetBuffers),
                                                 C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_int64, _P]),
+    "oige_newhand_cabinet_post_physics": (C.c_int, [C.POINTER(NewhandCabinetParams), C.POINTER(NewhandCabinetState),
+                                                    C.POINTER(NewhandCabinetBuffers), C.c_int64, C.c_uint32, _P]),
+    "oige_newhand_cabinet_pre_physics": (C.c_int, [C.POINTER(NewhandCabinetParams), _P, C.POINTER(NewhandCabinetBuffers),
+                                                   C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_uint32, _P]),
+    "oige_newhand_cabinet_reset_idx": (C.c_int, [C.POINTER(NewhandCabinetParams), C.POINTER(NewhandCabinetBuffers),
+                                                 C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_int64, _P]),
     "oige_observer_accumulate": (C.c_int, [C.POINTER(ObserverBatch), _P, _P, _P]),
     "oige_observer_means": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),

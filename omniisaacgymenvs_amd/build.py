@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liboige_hip.so")
-SOURCES = ["oige_core.hip", "locomotion.hip", "cartpole.hip", "hand.hip", "anymal_terrain.hip", "dr_noise.hip", "anymal.hip", "quadcopter.hip", "ball_balance.hip", "ingenuity.hip", "crazyflie.hip", "franka_cabinet.hip", "observer.hip"]
+SOURCES = ["oige_core.hip", "locomotion.hip", "cartpole.hip", "hand.hip", "anymal_terrain.hip", "dr_noise.hip", "anymal.hip", "quadcopter.hip", "ball_balance.hip", "ingenuity.hip", "crazyflie.hip", "franka_cabinet.hip", "newhand_cabinet.hip", "observer.hip"]
 HEADERS = ["oige_common.hpp", "oige_math.hpp", "oige_tile.hpp", os.path.join("..", "..", "include", "oige_hip.h")]
 FLAGS = [
     "--offload-arch=gfx950",

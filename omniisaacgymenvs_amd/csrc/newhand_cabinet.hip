@@ -1,0 +1,453 @@
+// TomoDJnewhandCabinet / TomoDJnewhandTendonCabinet / TomoSPCnewhandCabinet per-step task math for gfx950 (MI355X) --
+// SURVEY.md 8f rank 4.
+//
+// Replaces /root/reference/omniisaacgymenvs/tasks/tomodj_newhand_cabinet.py (26 DOFs), tasks/tomodj_newhandTendon_cabinet.py
+// (26 DOFs, 22 actuated, terminate_buf) and tasks/tomospc_newhand_cabinet.py (25 DOFs) behind their unchanged task method
+// contract: get_observations (five drawer + five fingertip keypoints), calculate_metrics (compute_*_reward), is_done,
+// pre_physics_step, reset_idx.
+//
+// post_physics: one wavefront per tile of 64 envs, HBM-bound.  Algorithmic bytes per env-step at D DOFs, A actions:
+//   R hand_rot 16 + 5 x (finger pos 12 + rot 16) + drawer 28 + dof_pos 4D + dof_vel 4D + cabinet rows 32 + actions 4A +
+//   progress 8 + reset 8 (+ terminate 8);  W obs 4(2D+5) + rew 4 + reset 8 + progress 8 + keypoints 120 (+ terminate 8).
+//   D = A = 26: 544 + 368 = 912.  The (N,D) / (N,A) inputs arrive as lane-linear float4 runs and are transposed through the
+//   (64 x (2D+5)) observation tile in LDS (odd row stride), which then streams out as one contiguous run.
+// pre_physics: one workgroup per 256 envs; flagged envs re-draw their joint positions on dense lanes and store their target
+//   rows, then the group's 256 x A actions are walked lane-linear, each integrating its joint's target.
+#include "oige_common.hpp"
+#include "oige_math.hpp"
+#include "oige_tile.hpp"
+
+namespace oige {
+
+constexpr int NMAX = OIGE_NEWHAND_MAX_DOFS;  // 26
+constexpr int NK = OIGE_NEWHAND_KEYPOINTS;   // 5
+
+struct NhPost {
+  oige_newhand_cabinet_params p;
+  oige_newhand_cabinet_state s;
+  oige_newhand_cabinet_buffers b;
+  int64_t n;
+  uint32_t stages;
+};
+
+OIGE_DEV f3 nh_f3(const float (&v)[3]) { return f3{v[0], v[1], v[2]}; }
+OIGE_DEV float nh_sign(const float x) { return (x != x) ? x : (float)((x > 0.0f) - (x < 0.0f)); }  // torch.sign
+OIGE_DEV f3 nh_keypoint(const q4 rot, const f3 pos, const f3 off) {  // tf_combine(rot, pos, identity, off)[1]
+  const f3 r = quat_apply(rot, off);
+  return f3{r.x + pos.x, r.y + pos.y, r.z + pos.z};
+}
+
+template <int D, int A, bool FULL>
+__device__ __forceinline__ void nh_post_tile(const NhPost& a, float* __restrict__ tile, int64_t t, int nv) {
+  constexpr int FO = 2 * D + 5;
+  const oige_newhand_cabinet_params& p = a.p;
+  const int lane = lane_id();
+  const int64_t env0 = t * TILE;
+  const int64_t env = env0 + lane;
+  const bool live = FULL || lane < nv;
+  const bool do_progress = a.stages & OIGE_STAGE_PROGRESS, do_obs = a.stages & OIGE_STAGE_OBS;
+  const bool do_metrics = a.stages & OIGE_STAGE_METRICS, do_done = a.stages & OIGE_STAGE_DONE;
+  const bool term = p.terminate_on_limits != 0;
+  const bool need_scaled = do_obs || (do_done && term);
+  const bool need_points = do_obs || do_metrics;
+
+  f3 dpos{0.f, 0.f, 0.f}, fpos[NK];
+  q4 drot{1.f, 0.f, 0.f, 0.f}, hrot{1.f, 0.f, 0.f, 0.f}, frot[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) { fpos[k] = f3{0.f, 0.f, 0.f}; frot[k] = q4{1.f, 0.f, 0.f, 0.f}; }
+  float cab3 = 0.f, cabv3 = 0.f;
+  int64_t progress = 0, reset = 0, term_in = 0;
+  if (live) {
+    if (need_points) {
+      const float* d3 = a.s.drawer_pos + env * 3;
+      dpos = f3{d3[0], d3[1], d3[2]};
+      const float4 dr = *reinterpret_cast<const float4*>(a.s.drawer_rot + env * 4);
+      drot = q4{dr.x, dr.y, dr.z, dr.w};
+#pragma unroll
+      for (int k = 0; k < NK; ++k) {
+        const float* f = a.s.finger_pos[k] + env * 3;
+        fpos[k] = f3{f[0], f[1], f[2]};
+        const float4 fr = *reinterpret_cast<const float4*>(a.s.finger_rot[k] + env * 4);
+        frot[k] = q4{fr.x, fr.y, fr.z, fr.w};
+      }
+    }
+    if (do_metrics) {
+      const float4 hr = *reinterpret_cast<const float4*>(a.s.hand_rot + env * 4);
+      hrot = q4{hr.x, hr.y, hr.z, hr.w};
+      if (term) term_in = a.b.terminate_buf[env];
+    }
+    cab3 = a.s.cabinet_dof_pos[env * 4 + 3];
+    if (do_obs) cabv3 = a.s.cabinet_dof_vel[env * 4 + 3];
+    if (do_progress || do_done) progress = a.b.progress_buf[env];
+    if (do_done) reset = a.b.reset_buf[env];
+  }
+  if (do_progress) progress += 1;  // rl_task.py:289
+
+  f3 kd[NK], kf[NK];
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    kd[k] = nh_keypoint(drot, dpos, nh_f3(p.drawer_local_keypoint_offsets[k]));
+    kf[k] = nh_keypoint(frot[k], fpos[k], k == 0 ? nh_f3(p.local_thumb_pose_pos) : nh_f3(p.local_another_finger_pose_pos));
+  }
+
+  float* row = tile + lane * FO;
+  float action_penalty = 0.0f;
+  if (do_metrics) {  // torch.sum(actions ** 2, dim=-1): the env's A actions through the tile
+    Chunk<A> c_act;
+    load_chunk<A, FULL>(c_act, a.b.actions + env0 * A, nv * A);
+    scatter_chunk<A, FO, 0, false>(c_act, tile, 1.0f);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < A; ++j) action_penalty += row[j] * row[j];
+    __syncthreads();
+  }
+  bool terminate_new = false;
+  if (need_scaled) {
+    Chunk<D> c_pos;
+    load_chunk<D, FULL>(c_pos, a.s.dof_pos + env0 * D, nv * D);
+    scatter_chunk<D, FO, 0, false>(c_pos, tile, 1.0f);
+    if (do_obs) {
+      Chunk<D> c_vel;
+      load_chunk<D, FULL>(c_vel, a.s.dof_vel + env0 * D, nv * D);
+      scatter_chunk<D, FO, D, true>(c_vel, tile, p.dof_vel_scale);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float sc = (2.0f * (row[j] - p.dof_lower[j])) / (p.dof_upper[j] - p.dof_lower[j]) - 1.0f;
+      row[j] = sc;
+      terminate_new |= (sc < -1.05f) | (sc > 1.05f);
+    }
+    if (do_obs) {
+      f3 tt{0.f, 0.f, 0.f};  // torch.sum(keypoints_drawer - keypoints_finger, dim=1)
+#pragma unroll
+      for (int k = 0; k < NK; ++k) { tt.x += kd[k].x - kf[k].x; tt.y += kd[k].y - kf[k].y; tt.z += kd[k].z - kf[k].z; }
+      row[2 * D] = tt.x; row[2 * D + 1] = tt.y; row[2 * D + 2] = tt.z;
+      row[2 * D + 3] = cab3; row[2 * D + 4] = cabv3;
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+          if (a.b.keypoints_finger) { float* o = a.b.keypoints_finger + (env * NK + k) * 3; o[0] = kf[k].x; o[1] = kf[k].y; o[2] = kf[k].z; }
+          if (a.b.keypoints_drawer) { float* o = a.b.keypoints_drawer + (env * NK + k) * 3; o[0] = kd[k].x; o[1] = kd[k].y; o[2] = kd[k].z; }
+        }
+      }
+    }
+  }
+  if (do_metrics) {
+    float dk[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) dk[k] = norm3(f3{kd[k].x - kf[k].x, kd[k].y - kf[k].y, kd[k].z - kf[k].z});
+    const float d = ((dk[1] + dk[2]) + dk[3]) + dk[4];
+    const float dist_reward = (-(d + dk[0])) / 2.0f;
+    const f3 axis1 = quat_apply(hrot, nh_f3(p.left_hand_forward_axis)), axis2 = quat_apply(drot, nh_f3(p.drawer_inward_axis));
+    const f3 axis3 = quat_apply(hrot, nh_f3(p.left_hand_up_axis)), axis4 = quat_apply(drot, nh_f3(p.drawer_up_axis));
+    const float dot1 = dot3(axis1, axis2), dot2 = dot3(axis3, axis4);
+    float rot_reward = 0.5f * (nh_sign(dot1) * (dot1 * dot1) + nh_sign(dot2) * (dot2 * dot2));
+    if (p.rot_reward_thresholds) {
+      rot_reward = (rot_reward < 0.6f) ? 0.0f : rot_reward;
+      rot_reward = (rot_reward >= 0.8f) ? 2.0f * rot_reward : rot_reward;
+    }
+    bool inside = true;
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const float dx = kf[k].x - dpos.x;
+      inside = inside && (dx > p.around_lower) && (dx < p.around_upper);
+    }
+    const float around = inside ? 0.5f : 0.0f;
+    const float open_reward = cab3 * around + cab3;
+    float rew = p.dist_reward_scale * dist_reward + p.rot_reward_scale * rot_reward;
+    rew = rew + p.around_handle_reward_scale * around;
+    rew = rew + p.open_reward_scale * open_reward;
+    rew = rew - p.action_penalty_scale * action_penalty;
+    rew = (cab3 > 0.01f) ? rew + 0.5f : rew;
+    rew = (cab3 > 0.1f) ? rew + around : rew;
+    rew = (cab3 > 0.19f) ? rew + (2.0f * around) : rew;
+    if (term) rew = (term_in == 1) ? -100.0f : rew;
+    if (live) a.b.rew_buf[env] = rew;
+  }
+  if (do_done) {  // sticky
+    const bool now = (cab3 > 0.19f) | (progress >= (int64_t)p.max_episode_length - 1) | (term && terminate_new);
+    const bool r = (reset != 0) | now;
+    if (live) {
+      a.b.reset_buf[env] = now ? 1 : reset;
+      if (term) a.b.terminate_buf[env] = terminate_new ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(live && r);
+    if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
+  }
+  if (do_progress && live) a.b.progress_buf[env] = progress;
+  __syncthreads();
+  if (do_obs) store_tile<FO, FULL>(tile, a.b.obs_buf + env0 * FO, nv * FO);
+}
+
+template <int D, int A>
+__global__ __launch_bounds__(WAVE) void newhand_cabinet_post_kernel(const NhPost a) {
+  __shared__ __align__(16) float tile[TILE * (2 * D + 5)];
+  const int64_t t = blockIdx.x;
+  const int64_t left = a.n - t * TILE;
+  if (left >= TILE)
+    nh_post_tile<D, A, true>(a, tile, t, TILE);
+  else
+    nh_post_tile<D, A, false>(a, tile, t, (int)left);
+}
+
+// ---------------------------------------------------------------- pre_physics / reset
+struct NhPre {
+  oige_newhand_cabinet_params p;
+  oige_newhand_cabinet_buffers b;
+  oige_franka_cabinet_reset_io r;
+  const float* actions_in;
+  int64_t n;
+  uint32_t flags;
+};
+
+template <int D>
+__device__ __forceinline__ void nh_draws(const NhPre& a, int64_t i, float (&u)[NMAX + 2]) {
+#pragma unroll
+  for (uint32_t blk = 0; blk < (D + 3) / 4; ++blk) {
+    const u4 c{(uint32_t)i, blk, (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
+    const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
+    u[blk * 4 + 0] = u01(x.x); u[blk * 4 + 1] = u01(x.y); u[blk * 4 + 2] = u01(x.z); u[blk * 4 + 3] = u01(x.w);
+  }
+}
+
+// reset_idx for env i landing in compacted row k: view rows, target row, flags
+template <int D>
+__device__ __forceinline__ void nh_reset_rows(const NhPre& a, int64_t i, int64_t k, const float (&u)[NMAX + 2]) {
+  const oige_newhand_cabinet_params& p = a.p;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    const float pos = tensor_clamp(p.default_dof_pos[j] + 0.25f * (u[j] - 0.5f), p.dof_lower[j], p.dof_upper[j]);
+    a.r.dof_pos_out[k * D + j] = pos;
+    a.r.dof_vel_out[k * D + j] = 0.0f;
+    a.b.dof_targets[i * D + j] = pos;
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  *reinterpret_cast<float4*>(a.r.cabinet_dof_pos_out + k * 4) = z4;
+  *reinterpret_cast<float4*>(a.r.cabinet_dof_vel_out + k * 4) = z4;
+  const int P = p.num_props;
+  for (int j = 0; j < P; ++j) {
+    const int64_t src = i * P + j, dst = k * P + j;
+    a.r.prop_ids[dst] = src;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.r.prop_pos_out[dst * 3 + c] = a.r.default_prop_pos[src * 3 + c];
+    *reinterpret_cast<float4*>(a.r.prop_rot_out + dst * 4) = *reinterpret_cast<const float4*>(a.r.default_prop_rot + src * 4);
+  }
+  a.b.reset_buf[i] = 0;
+  a.b.progress_buf[i] = 0;
+  a.r.env_ids[k] = i;
+}
+
+template <int D, int A>
+__global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre a) {
+  __shared__ int lds4[GROUP_TILES];
+  __shared__ int s_list[GROUP];
+  __shared__ float s_lo[D], s_hi[D], s_rate[D];
+  __shared__ int s_act[A];
+  const oige_newhand_cabinet_params& p = a.p;
+  const int tid = threadIdx.x;
+  const int64_t g = blockIdx.x;
+  const int64_t env = g * GROUP + tid;
+  const int64_t G = num_groups(a.n);
+  const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
+  const bool live = env < a.n;
+  const bool flagged = live && a.b.reset_buf[env] != 0;
+  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
+  const int32_t k0 = group_offsets[g];
+  const int cnt = group_offsets[g + 1] - k0;
+  if (flagged) s_list[(int)(k - k0)] = tid;
+#pragma unroll
+  for (int j = 0; j < D; ++j)
+    if (tid == j) {
+      s_lo[j] = p.dof_lower[j];
+      s_hi[j] = p.dof_upper[j];
+      s_rate[j] = p.dof_speed_scales[j] * p.dt;  // left to right: speed_scales * dt * actions * action_scale
+    }
+#pragma unroll
+  for (int j = 0; j < A; ++j)
+    if (tid == 64 + j) s_act[j] = p.actuated_dof_indices[j];
+  __syncthreads();
+
+  if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env; its target row goes to global memory
+    const int64_t i = g * GROUP + s_list[tid];
+    float u[NMAX + 2];
+    nh_draws<D>(a, i, u);
+    nh_reset_rows<D>(a, i, (int64_t)k0 + tid, u);
+  }
+  __syncthreads();  // the reset envs' new target rows are visible to the whole workgroup
+
+  const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
+  const int total = (int)envs_here * A;
+  const int64_t abase = g * GROUP * A;
+  const bool clampa = a.flags & OIGE_PRE_CLAMP_ACTIONS;
+#pragma unroll 1
+  for (int it = 0; it < (GROUP * A / 4 + GROUP - 1) / GROUP; ++it) {
+    const int e = 4 * (it * GROUP + tid);
+    if (e >= total) continue;
+    float av[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = e + 3 < total;
+    if (vec) {
+      const float4 a4 = *reinterpret_cast<const float4*>(a.actions_in + abase + e);
+      av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+    } else {
+      for (int c = 0; c < 4; ++c)
+        if (e + c < total) av[c] = a.actions_in[abase + e + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ee = e + c;
+      if (ee >= total) continue;
+      const int il = ee / A, ja = ee - il * A;
+      const int j = s_act[ja];
+      if (clampa) av[c] = clamp_sym(av[c], p.clip_actions);
+      float* tp = a.b.dof_targets + (g * GROUP + il) * D + j;
+      *tp = tensor_clamp(*tp + (s_rate[j] * av[c]) * p.action_scale, s_lo[j], s_hi[j]);
+    }
+    if (vec) {
+      *reinterpret_cast<float4*>(a.b.actions + abase + e) = make_float4(av[0], av[1], av[2], av[3]);  // actions.clone()
+    } else {
+      for (int c = 0; c < 4; ++c)
+        if (e + c < total) a.b.actions[abase + e + c] = av[c];
+    }
+  }
+  if (g == 0 && tid == 0) {
+    *a.r.count = (int64_t)group_offsets[G];
+    *a.r.prop_count = (int64_t)group_offsets[G] * p.num_props;
+  }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void newhand_cabinet_reset_idx_kernel(const NhPre a, int64_t max_ids) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k == 0) *a.r.prop_count = *a.r.count * a.p.num_props;
+  if (k >= max_ids || k >= *a.r.count) return;
+  const int64_t i = a.r.env_ids[k];
+  if (i < 0 || i >= a.n) return;
+  float u[NMAX + 2];
+  if (a.r.u_dof) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) u[j] = a.r.u_dof[k * D + j];
+  } else {
+    nh_draws<D>(a, i, u);
+  }
+  nh_reset_rows<D>(a, i, k, u);
+}
+
+static int check_newhand(const oige_newhand_cabinet_params* p, const oige_newhand_cabinet_buffers* b, int64_t n, const char* who) {
+  OIGE_REQUIRE(p && b, "%s: null params/buffers", who);
+  OIGE_REQUIRE(n >= 0 && n < ((int64_t)1 << 31) / 128, "%s: num_envs %lld out of range", who, (long long)n);
+  OIGE_REQUIRE(p->num_props >= 0 && p->num_props <= 64, "%s: num_props %d out of range [0, 64]", who, p->num_props);
+  const bool ok = (p->num_dofs == 26 && (p->num_actions == 26 || p->num_actions == 22)) || (p->num_dofs == 25 && p->num_actions == 25);
+  OIGE_REQUIRE(ok, "%s: (num_dofs, num_actions) = (%d, %d) not supported: (26, 26), (26, 22) or (25, 25)", who, p->num_dofs, p->num_actions);
+  for (int j = 0; j < p->num_actions; ++j)
+    OIGE_REQUIRE(p->actuated_dof_indices[j] >= 0 && p->actuated_dof_indices[j] < p->num_dofs, "%s: actuated_dof_indices[%d] = %d out of range",
+                 who, j, p->actuated_dof_indices[j]);
+  OIGE_REQUIRE(!p->terminate_on_limits || b->terminate_buf, "%s: terminate_on_limits needs terminate_buf", who);
+  return OIGE_OK;
+}
+
+}  // namespace oige
+
+using namespace oige;
+
+extern "C" {
+
+int oige_newhand_cabinet_post_physics(const oige_newhand_cabinet_params* params, const oige_newhand_cabinet_state* state,
+                                      const oige_newhand_cabinet_buffers* buffers, int64_t num_envs, uint32_t stages,
+                                      oige_stream_t stream) {
+  if (int rc = check_newhand(params, buffers, num_envs, "newhand_cabinet_post_physics")) return rc;
+  OIGE_REQUIRE(state != nullptr, "newhand_cabinet_post_physics: null state");
+  OIGE_REQUIRE((stages & ~OIGE_STAGE_ALL) == 0 && stages != 0, "newhand_cabinet_post_physics: bad stages mask 0x%x", stages);
+  const oige_newhand_cabinet_state& s = *state;
+  const oige_newhand_cabinet_buffers& b = *buffers;
+  OIGE_REQUIRE(s.hand_rot && s.drawer_pos && s.drawer_rot && s.dof_pos && s.dof_vel && s.cabinet_dof_pos && s.cabinet_dof_vel,
+               "newhand_cabinet_post_physics: null state pointer");
+  for (int k = 0; k < NK; ++k)
+    OIGE_REQUIRE(s.finger_pos[k] && s.finger_rot[k] && aligned16(s.finger_rot[k]), "newhand_cabinet_post_physics: finger %d: null/unaligned pose", k);
+  OIGE_REQUIRE(b.obs_buf && b.rew_buf && b.reset_buf && b.progress_buf && b.actions, "newhand_cabinet_post_physics: null buffer pointer");
+  OIGE_REQUIRE(aligned16(s.hand_rot) && aligned16(s.drawer_rot) && aligned16(s.dof_pos) && aligned16(s.dof_vel) && aligned16(b.actions) &&
+                   aligned16(b.obs_buf),
+               "newhand_cabinet_post_physics: row buffers must be 16-byte aligned");
+  const int64_t T = num_tiles(num_envs);
+  if (T == 0) return OIGE_OK;
+  NhPost a;
+  a.p = *params;
+  a.s = s;
+  a.b = b;
+  a.n = num_envs;
+  a.stages = stages;
+  hipStream_t st = (hipStream_t)stream;
+  if (params->num_dofs == 25)
+    hipLaunchKernelGGL((newhand_cabinet_post_kernel<25, 25>), dim3((unsigned)T), dim3(WAVE), 0, st, a);
+  else if (params->num_actions == 22)
+    hipLaunchKernelGGL((newhand_cabinet_post_kernel<26, 22>), dim3((unsigned)T), dim3(WAVE), 0, st, a);
+  else
+    hipLaunchKernelGGL((newhand_cabinet_post_kernel<26, 26>), dim3((unsigned)T), dim3(WAVE), 0, st, a);
+  return check_launch("newhand_cabinet_post_kernel");
+}
+
+static int fill_newhand_pre(NhPre& a, const oige_newhand_cabinet_params* params, const oige_newhand_cabinet_buffers* buffers,
+                            const oige_franka_cabinet_reset_io* r, int64_t n, const char* who) {
+  if (int rc = check_newhand(params, buffers, n, who)) return rc;
+  OIGE_REQUIRE(r != nullptr, "%s: null reset_io", who);
+  const oige_newhand_cabinet_buffers& b = *buffers;
+  OIGE_REQUIRE(b.reset_buf && b.progress_buf && b.dof_targets, "%s: null buffer pointer", who);
+  OIGE_REQUIRE(r->env_ids && r->count && r->dof_pos_out && r->dof_vel_out && r->cabinet_dof_pos_out && r->cabinet_dof_vel_out && r->prop_count,
+               "%s: null reset pointer", who);
+  OIGE_REQUIRE(params->num_props == 0 || (r->default_prop_pos && r->default_prop_rot && r->prop_ids && r->prop_pos_out && r->prop_rot_out),
+               "%s: num_props > 0 needs default_prop_pos/rot, prop_ids, prop_pos_out, prop_rot_out", who);
+  OIGE_REQUIRE(aligned16(r->cabinet_dof_pos_out) && aligned16(r->cabinet_dof_vel_out) && aligned16(r->default_prop_rot) &&
+                   aligned16(r->prop_rot_out),
+               "%s: row buffers must be 16-byte aligned", who);
+  a.p = *params;
+  a.b = b;
+  a.r = *r;
+  a.n = n;
+  a.flags = 0;
+  a.actions_in = nullptr;
+  return OIGE_OK;
+}
+
+int oige_newhand_cabinet_pre_physics(const oige_newhand_cabinet_params* params, const float* actions_in,
+                                     const oige_newhand_cabinet_buffers* buffers,
+                                     const oige_franka_cabinet_reset_io* reset_io, int64_t num_envs, uint32_t flags,
+                                     oige_stream_t stream) {
+  NhPre a;
+  if (int rc = fill_newhand_pre(a, params, buffers, reset_io, num_envs, "newhand_cabinet_pre_physics")) return rc;
+  const oige_newhand_cabinet_buffers& b = *buffers;
+  OIGE_REQUIRE(actions_in && aligned16(actions_in) && b.actions && aligned16(b.actions), "newhand_cabinet_pre_physics: null/unaligned actions");
+  OIGE_REQUIRE(b.reset_workspace && aligned16(b.reset_workspace), "newhand_cabinet_pre_physics: null/unaligned workspace");
+  OIGE_REQUIRE(!reset_io->u_dof, "newhand_cabinet_pre_physics: pre-drawn noise goes through oige_newhand_cabinet_reset_idx");
+  a.actions_in = actions_in;
+  a.flags = flags;
+  const int64_t G = num_groups(num_envs);
+  if (G == 0) return OIGE_OK;
+  hipStream_t s = (hipStream_t)stream;
+  if (!(flags & OIGE_PRE_COUNTS_VALID))
+    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
+  if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
+  if (params->num_dofs == 25)
+    hipLaunchKernelGGL((newhand_cabinet_pre_kernel<25, 25>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  else if (params->num_actions == 22)
+    hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 22>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  else
+    hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 26>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  return check_launch("newhand_cabinet_pre_kernel");
+}
+
+int oige_newhand_cabinet_reset_idx(const oige_newhand_cabinet_params* params, const oige_newhand_cabinet_buffers* buffers,
+                                   const oige_franka_cabinet_reset_io* reset_io, int64_t num_envs, int64_t max_ids,
+                                   oige_stream_t stream) {
+  NhPre a;
+  if (int rc = fill_newhand_pre(a, params, buffers, reset_io, num_envs, "newhand_cabinet_reset_idx")) return rc;
+  OIGE_REQUIRE(max_ids >= 0 && max_ids <= num_envs, "newhand_cabinet_reset_idx: bad max_ids");
+  if (max_ids == 0) return OIGE_OK;
+  const dim3 grid((unsigned)((max_ids + 255) / 256));
+  if (params->num_dofs == 25)
+    hipLaunchKernelGGL(newhand_cabinet_reset_idx_kernel<25>, grid, dim3(256), 0, (hipStream_t)stream, a, max_ids);
+  else
+    hipLaunchKernelGGL(newhand_cabinet_reset_idx_kernel<26>, grid, dim3(256), 0, (hipStream_t)stream, a, max_ids);
+  return check_launch("newhand_cabinet_reset_idx_kernel");
+}
+
+}  // extern "C"

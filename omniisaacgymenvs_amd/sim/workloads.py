@@ -402,3 +402,51 @@ def load_franka_cabinet_state(task, st: Dict[str, Tensor]) -> None:
     task.franka_dof_targets.copy_(st["targets"].to(dev))
     task.progress_buf.copy_(st["progress"].to(dev))
     task.reset_buf.copy_(st["reset"].to(dev))
+
+
+def newhand_cabinet_state(n: int, env_pos: Tensor, lower: Tensor, upper: Tensor, num_actions: int, device="cpu", seed: int = 1234) -> Dict[str, Tensor]:
+    """Five-finger cabinet tasks: fingertips around the drawer handle (half of the envs within millimetres,
+    so that the around-handle test on all five x offsets fires), joint positions up to 3 % beyond their limits (Tendon's
+    terminate_buf), drawer joint U(0, 0.22) (done beyond 0.19)."""
+    g = _gen(device, seed)
+    f = dict(device=device, dtype=torch.float32, generator=g)
+    env_pos, lo, hi = env_pos.to(device), lower.to(device), upper.to(device)
+    D = lo.shape[0]
+    ident = torch.tensor([1.0, 0.0, 0.0, 0.0], device=device)
+    unit = lambda: torch.nn.functional.normalize(torch.randn(n, 4, **f), dim=-1)
+    drawer_pos = (env_pos + torch.tensor([0.35, 0.0, 0.4], device=device) + torch.randn(n, 3, **f) * 0.05).contiguous()
+    drawer_rot = torch.where(torch.rand(n, 1, **f) < 0.6, ident, unit()).contiguous()
+    near = drawer_pos + torch.tensor([0.29, 0.0, 0.01], device=device)
+    spread = torch.where(torch.rand(n, 1, **f) < 0.5, torch.tensor(0.006, device=device), torch.tensor(0.08, device=device))
+    return dict(
+        hand_rot=unit().contiguous(), drawer_pos=drawer_pos, drawer_rot=drawer_rot,
+        finger_pos=[(near + torch.randn(n, 3, **f) * spread).contiguous() for _ in range(5)],
+        finger_rot=[torch.where(torch.rand(n, 1, **f) < 0.5, ident, unit()).contiguous() for _ in range(5)],
+        dof_pos=(lo + (hi - lo) * (torch.rand(n, D, **f) * 1.06 - 0.03)).contiguous(), dof_vel=torch.randn(n, D, **f),
+        cabinet_dof_pos=torch.rand(n, 4, **f) * 0.22, cabinet_dof_vel=torch.randn(n, 4, **f) * 0.3,
+        actions=torch.rand(n, num_actions, **f) * 2.0 - 1.0, prev_actions=torch.rand(n, num_actions, **f) * 2.0 - 1.0,
+        targets=(lo + (hi - lo) * torch.rand(n, D, **f)).contiguous(),
+        progress=torch.randint(0, 498, (n,), device=device, generator=g, dtype=torch.int64),
+        reset=(torch.rand(n, **f) < 0.03).long(), terminate=(torch.rand(n, **f) < 0.05).long(),
+    )
+
+
+def load_newhand_cabinet_state(task, st: Dict[str, Tensor]) -> None:
+    from ..tasks.newhand_cabinet import FINGER_VIEWS
+
+    dev, rb, cab = task.device, task._robots, task._cabinets
+    rb._hands.orientations.copy_(st["hand_rot"].to(dev))
+    for v, p, q in zip(FINGER_VIEWS, st["finger_pos"], st["finger_rot"]):
+        getattr(rb, v).positions.copy_(p.to(dev))
+        getattr(rb, v).orientations.copy_(q.to(dev))
+    cab._drawers.positions.copy_(st["drawer_pos"].to(dev))
+    cab._drawers.orientations.copy_(st["drawer_rot"].to(dev))
+    rb.joint_positions.copy_(st["dof_pos"].to(dev))
+    rb.joint_velocities.copy_(st["dof_vel"].to(dev))
+    cab.joint_positions.copy_(st["cabinet_dof_pos"].to(dev))
+    cab.joint_velocities.copy_(st["cabinet_dof_vel"].to(dev))
+    task.actions.copy_(st["prev_actions"].to(dev))
+    task.robot_dof_targets.copy_(st["targets"].to(dev))
+    task.progress_buf.copy_(st["progress"].to(dev))
+    task.reset_buf.copy_(st["reset"].to(dev))
+    task.terminate_buf.copy_(st["terminate"].to(dev))

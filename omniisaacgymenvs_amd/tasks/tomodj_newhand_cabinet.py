@@ -1,0 +1,2 @@
+"""tasks/tomodj_newhand_cabinet.py of the reference: see newhand_cabinet.py (one shared mirror)."""
+from .newhand_cabinet import TomoDJnewhandCabinetTask  # noqa: F401

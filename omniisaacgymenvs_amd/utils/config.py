@@ -175,6 +175,15 @@ TASK_DEFAULTS["TomoSPCCabinet"] = {
     "sim": dict(_SIM, dt=0.0083, gravity=[0.0, 0.0, -9.81]),
 }
 
+# cfg/task/TomoDJnewhandCabinet.yaml, TomoDJnewhandTendonCabinet.yaml, TomoSPCnewhandCabinet.yaml (identical scalars)
+for _name in ("TomoDJnewhandCabinet", "TomoDJnewhandTendonCabinet", "TomoSPCnewhandCabinet"):
+    TASK_DEFAULTS[_name] = {
+        "name": _name,
+        "env": dict(TASK_DEFAULTS["FrankaCabinet"]["env"], aroundHandleRewardScale=2, distRewardScale=10, fingerCloseRewardScale=10,
+                    fingerDistRewardScale=15, openRewardScale=12.5, rotRewardScale=3),
+        "sim": dict(_SIM, dt=0.0083, gravity=[0.0, 0.0, -9.81]),
+    }
+
 # cfg/task/AnymalTerrain.yaml:5-103
 TASK_DEFAULTS["AnymalTerrain"] = {
     "name": "AnymalTerrain",

@@ -22,6 +22,8 @@ def make_task(name: str, n: int, device: str = "cuda:0", seed: int = 42, **env_o
     from omniisaacgymenvs_amd.tasks.crazyflie import CrazyflieTask
     from omniisaacgymenvs_amd.tasks.franka_cabinet import FrankaCabinetTask
     from omniisaacgymenvs_amd.tasks.tomodj_cabinet import TomoDJCabinetTask, TomoSPCCabinetTask
+    from omniisaacgymenvs_amd.tasks.newhand_cabinet import (TomoDJnewhandCabinetTask, TomoDJnewhandTendonCabinetTask,
+                                                            TomoSPCnewhandCabinetTask)
     from omniisaacgymenvs_amd.tasks.ingenuity import IngenuityTask
     from omniisaacgymenvs_amd.tasks.quadcopter import QuadcopterTask
     from omniisaacgymenvs_amd.tasks.anymal_terrain import AnymalTerrainTask
@@ -30,7 +32,8 @@ def make_task(name: str, n: int, device: str = "cuda:0", seed: int = 42, **env_o
     cls = {"Ant": AntLocomotionTask, "Humanoid": HumanoidLocomotionTask, "Cartpole": CartpoleTask,
            "ShadowHand": ShadowHandTask, "ShadowHandOpenAI_FF": ShadowHandTask, "AnymalTerrain": AnymalTerrainTask,
            "Anymal": AnymalTask, "AllegroHand": AllegroHandTask, "Quadcopter": QuadcopterTask, "BallBalance": BallBalanceTask, "Ingenuity": IngenuityTask, "Crazyflie": CrazyflieTask, "FrankaCabinet": FrankaCabinetTask, "TomoDJCabinet": TomoDJCabinetTask,
-            "TomoSPCCabinet": TomoSPCCabinetTask}[name]
+            "TomoSPCCabinet": TomoSPCCabinetTask, "TomoDJnewhandCabinet": TomoDJnewhandCabinetTask,
+            "TomoDJnewhandTendonCabinet": TomoDJnewhandTendonCabinetTask, "TomoSPCnewhandCabinet": TomoSPCnewhandCabinetTask}[name]
     cfg = global_config(sim_device=device, rl_device=device, seed=seed)
     sim_config = SimConfig(cfg, task_config(name, num_envs=n, **env_overrides))
     env = VecEnvRLGames(headless=True)

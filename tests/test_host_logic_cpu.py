@@ -24,7 +24,8 @@ def _flat(d, prefix=""):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="/root/reference not present (GPU box)")
-@pytest.mark.parametrize("name", ["Cartpole", "Ant", "Humanoid", "ShadowHand", "ShadowHandOpenAI_FF", "AnymalTerrain", "Anymal", "AllegroHand", "Quadcopter", "BallBalance", "Ingenuity", "Crazyflie", "FrankaCabinet", "TomoDJCabinet", "TomoSPCCabinet"])
+@pytest.mark.parametrize("name", ["Cartpole", "Ant", "Humanoid", "ShadowHand", "ShadowHandOpenAI_FF", "AnymalTerrain", "Anymal", "AllegroHand", "Quadcopter", "BallBalance", "Ingenuity", "Crazyflie", "FrankaCabinet", "TomoDJCabinet", "TomoSPCCabinet", "TomoDJnewhandCabinet",
+                                  "TomoDJnewhandTendonCabinet", "TomoSPCnewhandCabinet"])
 def test_task_defaults_carry_the_reference_yaml_values(name):
     """Every scalar env.* key we carry equals the reference YAML's value (hydra interpolations skipped)."""
     with open(os.path.join(REF_CFG, name + ".yaml")) as f:

@@ -1,0 +1,177 @@
+"""-m gpu parity tests: HIP five-finger cabinet path (TomoDJnewhand / TomoDJnewhandTendon / TomoSPCnewhand, through the C ABI)
+vs the CPU oracle (pinned to the three reference files by tests/test_oracle_pinned_newhand_cabinet.py).  Bar: reset /
+terminate flags, id lists, progress bit-exact; fp32 observations, keypoints, rewards, targets within 1e-5 rel / 1e-6 abs."""
+import pytest
+import torch
+
+from helpers import assert_close, assert_equal, make_task
+from omniisaacgymenvs_amd.sim import workloads
+from oracle import newhand_cabinet_oracle as no
+
+pytestmark = pytest.mark.gpu
+NAMES = ["TomoDJnewhandCabinet", "TomoDJnewhandTendonCabinet", "TomoSPCnewhandCabinet"]
+
+
+def _loaded(name, n, seed=1234):
+    env, task = make_task(name, n)
+    st = workloads.newhand_cabinet_state(n, task._env_pos.cpu(), task.robot_dof_lower_limits.cpu(), task.robot_dof_upper_limits.cpu(),
+                                         task.num_actions, device="cpu", seed=seed)
+    if n > 12:
+        st["progress"][:3] = torch.tensor([496, 497, 498])
+        st["cabinet_dof_pos"][3:9, 3] = torch.tensor([0.0099, 0.0101, 0.0999, 0.1001, 0.1899, 0.1901])
+    workloads.load_newhand_cabinet_state(task, st)
+    return env, task, st
+
+
+def _spec(task) -> no.NewhandSpec:
+    kw = dict(num_props=task.num_props)
+    if task.name == "TomoDJnewhandCabinet":
+        spec = no.tomodj_newhand_spec(**kw)
+    elif task.name == "TomoDJnewhandTendonCabinet":
+        spec = no.tomodj_newhand_tendon_spec(task.ACTUATED, **kw)
+    else:
+        spec = no.tomospc_newhand_spec(**kw)
+    assert spec.num_dofs == task.NUM_DOFS and spec.num_actions == task.num_actions and spec.default_dof_pos == list(task.DEFAULT_DOF_POS)
+    for k in ("dist_reward_scale", "rot_reward_scale", "around_handle_reward_scale", "open_reward_scale", "action_penalty_scale"):
+        assert getattr(spec, k) == getattr(task, k), k
+    assert torch.equal(torch.tensor(spec.drawer_local_keypoint_offsets), task.drawer_local_keypoint_offsets.cpu())
+    return spec
+
+
+def _oracle_buffers(task) -> no.NewhandBuffers:
+    c = lambda t: t.detach().cpu().clone()
+    return no.NewhandBuffers(c(task.obs_buf), c(task.rew_buf), c(task.reset_buf), c(task.progress_buf), c(task.actions),
+                             c(task.robot_dof_targets), c(task.keypoints_finger), c(task.keypoints_drawer), c(task.terminate_buf))
+
+
+def _limits(task):
+    return task.robot_dof_lower_limits.cpu(), task.robot_dof_upper_limits.cpu()
+
+
+@pytest.mark.parametrize("n", [1, 40, 64, 257, 4096])
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("name", NAMES)
+def test_post_physics_matches_oracle(n, fused, name):
+    env, task, st = _loaded(name, n)
+    task.fused = fused
+    spec, b = _spec(task), _oracle_buffers(task)
+    lo, hi = _limits(task)
+    no.post_physics(spec, b, st, lo, hi)
+    obs, rew, reset, _ = task.post_physics_step()
+    torch.cuda.synchronize()
+    assert_close(obs, b.obs_buf, "obs_buf")
+    assert_close(task.keypoints_finger, b.keypoints_finger, "keypoints_finger")
+    assert_close(task.keypoints_drawer, b.keypoints_drawer, "keypoints_drawer")
+    assert_equal(task.progress_buf, b.progress_buf, "progress_buf")
+    # flags and reward may flip where a scaled joint position / a keypoint offset sits within rounding of a threshold
+    sc = b.dof_pos_scaled
+    edge = ((sc.abs() - 1.05).abs() < 1e-5).any(-1) if spec.terminate_on_limits else torch.zeros(n, dtype=torch.bool)
+    dx = torch.stack([b.keypoints_finger[:, i, 0] - st["drawer_pos"][:, 0] for i in range(5)], -1)
+    edge_r = (((dx - spec.around_lower).abs() < 1e-6) | ((dx - spec.around_upper).abs() < 1e-6)).any(-1)
+    assert int(edge.sum()) + int(edge_r.sum()) <= max(2, n // 500)
+    assert_equal(reset[~edge], b.reset_buf[~edge], "reset_buf")
+    assert_close(rew[~edge_r], b.rew_buf[~edge_r], "rew_buf")
+    if spec.terminate_on_limits:
+        assert_equal(task.terminate_buf[~edge], b.terminate_buf[~edge], "terminate_buf")
+        assert bool((rew[st["terminate"].to(rew.device) == 1] == -100).all())
+        if n >= 257:
+            assert 0 < int(task.terminate_buf.sum()) < n
+    if n >= 4096:
+        inside = ((dx > spec.around_lower) & (dx < spec.around_upper)).all(-1)
+        assert int(inside.sum()) > 10
+    if n > 12:
+        assert int(reset[2]) == 1 and int(reset[8]) == 1
+
+
+@pytest.mark.parametrize("n", [1, 64, 300, 5000])
+@pytest.mark.parametrize("clamp", [False, True])
+@pytest.mark.parametrize("name", NAMES)
+def test_sync_free_pre_physics_matches_oracle(n, clamp, name):
+    env, task, st = _loaded(name, n)
+    for v in (task._robots, task._cabinets, task._props):
+        v.apply_resets = False
+    if n >= 64:
+        task.reset_buf[: n // 3] = 1
+    spec, b = _spec(task), _oracle_buffers(task)
+    lo, hi = _limits(task)
+    D, A = task.NUM_DOFS, task.num_actions
+    actions = torch.rand(n, A, generator=torch.Generator().manual_seed(5)) * 3 - 1.5
+    task.clamp_actions_in_kernel = clamp
+    want_actions = torch.clamp(actions, -task.clip_actions, task.clip_actions) if clamp else actions
+    task.pre_physics_step(actions.to(task.device))
+    torch.cuda.synchronize()
+    o = task._reset_out
+    k = int(o["count"].item())
+    u_dev = (o["dof_pos"][:k].cpu() - torch.tensor(spec.default_dof_pos)) / 0.25 + 0.5  # the in-kernel draws, where unclamped
+    ids, rows = no.pre_physics(spec, b, want_actions, lo, hi, task.robot_dof_speed_scales.cpu(), lambda i: u_dev.clone(),
+                               default_prop_pos=task.default_prop_pos.cpu(), default_prop_rot=task.default_prop_rot.cpu())
+    assert k == len(ids)
+    assert_equal(o["env_ids"][:k], ids, "env ids == reset_buf.nonzero()")
+    assert_equal(task.reset_buf, b.reset_buf, "reset_buf")
+    assert_equal(task.progress_buf, b.progress_buf, "progress_buf")
+    assert_equal(task.actions, b.actions, "actions")
+    assert_close(task.robot_dof_targets, b.dof_targets, "dof_targets")
+    if spec.actuated_dof_indices is not None:
+        passive = [j for j in range(D) if j not in spec.actuated_dof_indices]
+        keep = torch.ones(n, dtype=torch.bool)
+        keep[ids] = False
+        assert_equal(task.robot_dof_targets[:, passive][keep], st["targets"][:, passive][keep], "passive joints' targets untouched")
+        vals, jidx = task._robots.joint_position_targets_subset
+        assert list(jidx) == spec.actuated_dof_indices and vals.shape == (n, A)
+    if rows is not None:
+        dp = o["dof_pos"][:k].cpu()
+        assert bool(((dp >= lo) & (dp <= hi)).all())
+        inside = (dp > lo + 1e-6) & (dp < hi - 1e-6)
+        assert bool(((u_dev >= -1e-5) & (u_dev < 1.0 + 1e-5))[inside].all()), "in-kernel draws are U[0,1)"
+        assert_close(o["dof_pos"][:k], rows["dof_pos"], "dof_pos rows")
+        assert float(o["dof_vel"][:k].abs().max()) == 0.0 and float(o["cabinet_dof_pos"][:k].abs().max()) == 0.0
+        P = task.num_props
+        assert int(o["prop_count"].item()) == k * P
+        assert_equal(o["prop_ids"][: k * P], rows["prop_ids"], "prop ids")
+        assert_equal(o["prop_pos"][: k * P], rows["prop_pos"], "prop_pos rows")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_reference_flow_replays_torch_rng(name):
+    n = 500
+    env, task, st = _loaded(name, n)
+    task.sync_free = False
+    task.reset_buf[::7] = 1
+    spec, b = _spec(task), _oracle_buffers(task)
+    lo, hi = _limits(task)
+    D, A = task.NUM_DOFS, task.num_actions
+    actions = torch.rand(n, A, generator=torch.Generator().manual_seed(6)) * 2 - 1
+    torch.manual_seed(77)
+    task.pre_physics_step(actions.to(task.device))
+    torch.cuda.synchronize()
+    torch.manual_seed(77)
+    ids, rows = no.pre_physics(spec, b, actions, lo, hi, task.robot_dof_speed_scales.cpu(),
+                               lambda i: torch.rand((len(i), D), device=task.device).cpu(), default_prop_pos=task.default_prop_pos.cpu(),
+                               default_prop_rot=task.default_prop_rot.cpu())
+    assert_equal(task.reset_buf, b.reset_buf, "reset_buf")
+    assert_close(task.robot_dof_targets, b.dof_targets, "dof_targets")
+    assert_close(task._robots.joint_positions[ids.to(task.device)], rows["dof_pos"], "joint positions written through the setter")
+
+
+def test_full_size_properties_and_aliases():
+    n = 1 << 19
+    env, task, st = _loaded("TomoDJnewhandTendonCabinet", n)
+    assert task.tomodj_dof_targets.data_ptr() == task.robot_dof_targets.data_ptr() and task._tomodjs is task._robots
+    D = task.NUM_DOFS
+    obs, rew, reset, _ = task.post_physics_step()
+    torch.cuda.synchronize()
+    assert_equal(obs[:, 2 * D + 3], st["cabinet_dof_pos"][:, 3], "obs drawer joint position")
+    assert_close(obs[:, D:2 * D], st["dof_vel"] * 0.1, "obs joint velocities")
+    assert_close(obs[:, 2 * D:2 * D + 3], (task.keypoints_drawer - task.keypoints_finger).sum(1), "to_target == summed keypoint differences")
+    outside = (obs[:, :D].abs() > 1.05).any(-1)
+    assert_equal(task.terminate_buf, outside.long(), "terminate_buf == any scaled joint beyond +-1.05")
+    assert bool((reset[outside] == 1).all())
+    want = reset.nonzero().squeeze(-1).clone()
+    for v in (task._robots, task._cabinets, task._props):
+        v.apply_resets = False
+    task.pre_physics_step(st["actions"].to(task.device))
+    torch.cuda.synchronize()
+    o = task._reset_out
+    assert int(o["count"].item()) == want.numel() and want.numel() > 0
+    assert_equal(o["env_ids"][: want.numel()], want, "env ids == nonzero()")
+    assert int(task.reset_buf.sum().item()) == 0
