@@ -18,7 +18,8 @@ from collections import defaultdict
 
 DEFAULT_ENVS = {"Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18, "Anymal": 1 << 20,
                 "AllegroHand": 1 << 20, "Quadcopter": 1 << 20, "BallBalance": 1 << 20, "Ingenuity": 1 << 20,
-                "Crazyflie": 1 << 20, "FrankaCabinet": 1 << 20}  # bench.py defaults
+                "Crazyflie": 1 << 20, "FrankaCabinet": 1 << 20, "TomoDJCabinet": 1 << 20, "TomoSPCCabinet": 1 << 20,
+                "TomoDJnewhandCabinet": 1 << 19, "TomoDJnewhandTendonCabinet": 1 << 19, "TomoSPCnewhandCabinet": 1 << 19}  # bench.py defaults
 
 
 def short(name: str) -> str:
@@ -76,7 +77,10 @@ def main() -> None:
                 "Anymal": ["anymal_flat_post_kernel"], "AllegroHand": ["allegro_post_kernel"],
                 "Quadcopter": ["quadcopter_post_kernel"], "BallBalance": ["ball_balance_post_kernel"],
                 "Ingenuity": ["ingenuity_post_kernel"], "Crazyflie": ["crazyflie_post_kernel"],
-                "FrankaCabinet": ["franka_cabinet_post_kernel"]}
+                "FrankaCabinet": ["franka_cabinet_post_kernel"],
+                "TomoDJCabinet": ["franka_cabinet_post_kernel"], "TomoSPCCabinet": ["franka_cabinet_post_kernel"],
+                "TomoDJnewhandCabinet": ["newhand_cabinet_post_kernel"], "TomoDJnewhandTendonCabinet": ["newhand_cabinet_post_kernel"],
+                "TomoSPCnewhandCabinet": ["newhand_cabinet_post_kernel"]}
     traffic = {}
     for task, ks in pmc.items():
         fetch = write = 0.0
