@@ -243,7 +243,7 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   __shared__ int lds4[GROUP_TILES];
   __shared__ int s_list[GROUP];
   __shared__ float s_lo[D], s_hi[D], s_rate[D];
-  __shared__ int s_act[A];
+  __shared__ int s_inv[D];  // joint -> action column, -1: not actuated
   const oige_newhand_cabinet_params& p = a.p;
   const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
@@ -263,9 +263,13 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
       s_hi[j] = p.dof_upper[j];
       s_rate[j] = p.dof_speed_scales[j] * p.dt;  // left to right: speed_scales * dt * actions * action_scale
     }
+  if (tid >= 64 && tid < 64 + D) {
+    int inv = -1;
 #pragma unroll
-  for (int j = 0; j < A; ++j)
-    if (tid == 64 + j) s_act[j] = p.actuated_dof_indices[j];
+    for (int j = 0; j < A; ++j)
+      if (p.actuated_dof_indices[j] == tid - 64) inv = j;
+    s_inv[tid - 64] = inv;
+  }
   __syncthreads();
 
   if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env; its target row goes to global memory
@@ -277,37 +281,63 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   __syncthreads();  // the reset envs' new target rows are visible to the whole workgroup
 
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
-  const int total = (int)envs_here * A;
-  const int64_t abase = g * GROUP * A;
   const bool clampa = a.flags & OIGE_PRE_CLAMP_ACTIONS;
-#pragma unroll 1
-  for (int it = 0; it < (GROUP * A / 4 + GROUP - 1) / GROUP; ++it) {
-    const int e = 4 * (it * GROUP + tid);
-    if (e >= total) continue;
-    float av[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool vec = e + 3 < total;
-    if (vec) {
-      const float4 a4 = *reinterpret_cast<const float4*>(a.actions_in + abase + e);
-      av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
-    } else {
-      for (int c = 0; c < 4; ++c)
-        if (e + c < total) av[c] = a.actions_in[abase + e + c];
-    }
+  {  // actions.clone() (+ the wrapper's clamp): the group's 256 x A floats as float4 pieces
+    const int total = (int)envs_here * A;
+    const int64_t abase = g * GROUP * A;
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int ee = e + c;
-      if (ee >= total) continue;
-      const int il = ee / A, ja = ee - il * A;
-      const int j = s_act[ja];
-      if (clampa) av[c] = clamp_sym(av[c], p.clip_actions);
-      float* tp = a.b.dof_targets + (g * GROUP + il) * D + j;
-      *tp = tensor_clamp(*tp + (s_rate[j] * av[c]) * p.action_scale, s_lo[j], s_hi[j]);
+    for (int it = 0; it < (GROUP * A / 4 + GROUP - 1) / GROUP; ++it) {
+      const int e = 4 * (it * GROUP + tid);
+      if (e >= total) continue;
+      if (e + 3 < total) {
+        float4 v = *reinterpret_cast<const float4*>(a.actions_in + abase + e);
+        if (clampa) {
+          v.x = clamp_sym(v.x, p.clip_actions); v.y = clamp_sym(v.y, p.clip_actions);
+          v.z = clamp_sym(v.z, p.clip_actions); v.w = clamp_sym(v.w, p.clip_actions);
+        }
+        *reinterpret_cast<float4*>(a.b.actions + abase + e) = v;
+      } else {
+        for (int c = 0; c < 4; ++c)
+          if (e + c < total) {
+            const float v = a.actions_in[abase + e + c];
+            a.b.actions[abase + e + c] = clampa ? clamp_sym(v, p.clip_actions) : v;
+          }
+      }
     }
-    if (vec) {
-      *reinterpret_cast<float4*>(a.b.actions + abase + e) = make_float4(av[0], av[1], av[2], av[3]);  // actions.clone()
-    } else {
-      for (int c = 0; c < 4; ++c)
-        if (e + c < total) a.b.actions[abase + e + c] = av[c];
+  }
+  {  // targets: the group's 256 x D floats as float4 pieces; joint j integrates action column s_inv[j] (none: unchanged)
+    const int total = (int)envs_here * D;
+    const int64_t tbase = g * GROUP * D;
+#pragma unroll
+    for (int it = 0; it < (GROUP * D / 4 + GROUP - 1) / GROUP; ++it) {
+      const int e = 4 * (it * GROUP + tid);
+      if (e >= total) continue;
+      float tv[4] = {0.f, 0.f, 0.f, 0.f};
+      const bool vec = e + 3 < total;
+      if (vec) {
+        const float4 t4 = *reinterpret_cast<const float4*>(a.b.dof_targets + tbase + e);
+        tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
+      } else {
+        for (int c = 0; c < 4; ++c)
+          if (e + c < total) tv[c] = a.b.dof_targets[tbase + e + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int ee = e + c;
+        if (ee >= total) continue;
+        const int il = ee / D, jj = ee - il * D;
+        const int ja = s_inv[jj];
+        if (ja < 0) continue;
+        float av = a.actions_in[(g * GROUP + il) * A + ja];
+        if (clampa) av = clamp_sym(av, p.clip_actions);
+        tv[c] = tensor_clamp(tv[c] + (s_rate[jj] * av) * p.action_scale, s_lo[jj], s_hi[jj]);
+      }
+      if (vec) {
+        *reinterpret_cast<float4*>(a.b.dof_targets + tbase + e) = make_float4(tv[0], tv[1], tv[2], tv[3]);
+      } else {
+        for (int c = 0; c < 4; ++c)
+          if (e + c < total) a.b.dof_targets[tbase + e + c] = tv[c];
+      }
     }
   }
   if (g == 0 && tid == 0) {

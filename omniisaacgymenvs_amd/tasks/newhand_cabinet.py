@@ -137,6 +137,7 @@ class _NewhandCabinetTask(RLTask):
         f = dict(dtype=torch.float32, device=dev)
         if self.ACTUATED is not None:
             self.actuated_dof_indices = self._robots.actuated_dof_indices
+            self._actuated_index = torch.tensor(self.actuated_dof_indices, dtype=torch.int64, device=dev)
         self.num_robot_dofs = self._robots.num_dof
         self.robot_dof_pos = torch.zeros((n, D), device=dev)
         dof_limits = self._robots.get_dof_limits()
@@ -334,7 +335,9 @@ class _NewhandCabinetTask(RLTask):
         if self.ACTUATED is None:
             self._robots.set_joint_position_targets(self.robot_dof_targets)
         else:  # Tendon: only the actuated joints' targets are handed over (joint_indices=...)
-            self._robots.set_joint_position_targets(self.robot_dof_targets[:, self.actuated_dof_indices], joint_indices=self.actuated_dof_indices)
+            # (a Python list as index would be turned into a device tensor on every call: keep one)
+            self._robots.set_joint_position_targets(self.robot_dof_targets.index_select(1, self._actuated_index),
+                                                    joint_indices=self.actuated_dof_indices)
 
     def reset_idx(self, env_ids):
         num = len(env_ids)
