@@ -300,6 +300,8 @@ typedef struct oige_hand_reset_io {
   float* object_vel_out;         /* out (ne,6) zeros */
   float* dof_pos_out;            /* out (ne,24) also the position targets (:433-436) */
   float* dof_vel_out;            /* out (ne,24) */
+  const uint64_t* step_ptr; /* NULL, or a device scalar read INSTEAD of `step` (HIP-graph replay), as
+                               oige_locomotion_reset_io.step_ptr */
 } oige_hand_reset_io;
 
 /* pre_physics_step (:314-362): both compactions, reset_target_pose of goal ids, reset_idx of env
@@ -406,6 +408,8 @@ typedef struct oige_anymal_reset_io {
   float* base_vel_out;       /* out (n,6) */
   float* dof_pos_out;        /* out (n,12) */
   float* dof_vel_out;        /* out (n,12) */
+  const uint64_t* step_ptr; /* NULL, or a device scalar read INSTEAD of `step` (HIP-graph replay), as
+                               oige_locomotion_reset_io.step_ptr */
 } oige_anymal_reset_io;
 
 /* One decimation sub-step of pre_physics_step (:398-403):
@@ -481,6 +485,8 @@ typedef struct oige_anymal_flat_reset_io {
   float* root_pos_out;           /* out (n,3) */
   float* root_rot_out;           /* out (n,4) */
   float* root_vel_out;           /* out (n,6) zeros */
+  const uint64_t* step_ptr; /* NULL, or a device scalar read INSTEAD of `step` (HIP-graph replay), as
+                               oige_locomotion_reset_io.step_ptr */
 } oige_anymal_flat_reset_io;
 
 /* RLTask.post_physics_step (rl_task.py:289-295) for AnymalTask: progress += 1, get_observations (:143-178),
@@ -618,6 +624,8 @@ typedef struct oige_quadcopter_reset_io {
   float* root_pos_out;           /* out (n,3) */
   float* root_rot_out;           /* out (n,4) */
   float* root_vel_out;           /* out (n,6) zeros */
+  const uint64_t* step_ptr; /* NULL, or a device scalar read INSTEAD of `step` (HIP-graph replay), as
+                               oige_locomotion_reset_io.step_ptr */
 } oige_quadcopter_reset_io;
 
 /* pre_physics_step (:143-175): compaction, reset_idx of the flagged envs, DOF-target and thrust integration + clamps, z
@@ -689,6 +697,8 @@ typedef struct oige_ball_balance_reset_io {
   float* bot_rot_out;                  /* out (n,4) */
   float* bot_vel_out;                  /* out (n,6) */
   float* dof_pos_out;                  /* out (n,num_dof) */
+  const uint64_t* step_ptr; /* NULL, or a device scalar read INSTEAD of `step` (HIP-graph replay), as
+                               oige_locomotion_reset_io.step_ptr */
 } oige_ball_balance_reset_io;
 
 /* pre_physics_step (:187-206): compaction, reset_idx of the flagged envs, integrate + clamp the position targets, zero
@@ -760,6 +770,8 @@ typedef struct oige_ingenuity_reset_io {
   int64_t* target_count;         /* out device scalar */
   float* ball_pos_out;           /* out (m,3) target + env_pos, z + 0.4 */
   float* ball_rot_out;           /* out (m,4) */
+  const uint64_t* step_ptr; /* NULL, or a device scalar read INSTEAD of `step` (HIP-graph replay), as
+                               oige_locomotion_reset_io.step_ptr */
 } oige_ingenuity_reset_io;
 
 /* pre_physics_step (:149-190): both compactions, reset_idx, set_targets, thrust vectors, rotor speeds.             */
@@ -892,6 +904,8 @@ typedef struct oige_cartpole_reset_io {
   int64_t* count;      /* out device scalar */
   float* dof_pos_out;  /* out (n,num_dof) */
   float* dof_vel_out;  /* out (n,num_dof) */
+  const uint64_t* step_ptr; /* NULL, or a device scalar read INSTEAD of `step` (HIP-graph replay), as
+                               oige_locomotion_reset_io.step_ptr */
 } oige_cartpole_reset_io;
 
 /* pre_physics_step (:108-122): compaction, reset_idx (:124-144), forces[:, cart] = max_effort * a[:,0] */
@@ -993,6 +1007,8 @@ typedef struct oige_franka_cabinet_reset_io {
   int64_t* prop_count;           /* out device scalar = count * num_props */
   float* prop_pos_out;           /* out (n*num_props,3) */
   float* prop_rot_out;           /* out (n*num_props,4) */
+  const uint64_t* step_ptr; /* NULL, or a device scalar read INSTEAD of `step` (HIP-graph replay), as
+                               oige_locomotion_reset_io.step_ptr */
 } oige_franka_cabinet_reset_io;
 
 /* pre_physics_step (:360-373): compaction, reset_idx of the flagged envs, actions clone, then for ALL envs (the reset ones

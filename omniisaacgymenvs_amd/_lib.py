@@ -69,8 +69,8 @@ class CartpoleBuffers(C.Structure):
 
 
 class CartpoleResetIO(C.Structure):
-    _fields_ = [("u", _fp), ("seed", C.c_uint64), ("step", C.c_uint64), ("env_ids", _fp), ("count", _fp),
-                ("dof_pos_out", _fp), ("dof_vel_out", _fp)]
+    _fields_ = ([("u", _fp), ("seed", C.c_uint64), ("step", C.c_uint64), ("env_ids", _fp), ("count", _fp),
+                ("dof_pos_out", _fp), ("dof_vel_out", _fp)]) + [("step_ptr", _fp)]
 
 
 class HandParams(C.Structure):
@@ -104,7 +104,7 @@ class HandBuffers(C.Structure):
 
 
 class HandResetIO(C.Structure):
-    _fields_ = [
+    _fields_ = ([
         ("object_init_pos", _fp), ("goal_init_pos", _fp), ("env_pos", _fp),
         ("u_goal", _fp), ("u_reset", _fp), ("u_reset_goal", _fp),
         ("seed", C.c_uint64), ("step", C.c_uint64),
@@ -112,7 +112,8 @@ class HandResetIO(C.Structure):
         ("env_ids", _fp), ("count", _fp), ("r_goal_world_pos_out", _fp), ("r_goal_rot_out", _fp),
         ("object_pos_out", _fp), ("object_rot_out", _fp), ("object_vel_out", _fp),
         ("dof_pos_out", _fp), ("dof_vel_out", _fp),
-    ]
+    ]) + [("step_ptr", _fp)]
+
 
 HAND_OBS_OPENAI, HAND_OBS_FULL = 0, 2
 HAND_OBS_ALLEGRO_FULL_NO_VEL, HAND_OBS_ALLEGRO_FULL = 3, 4
@@ -148,12 +149,12 @@ class AnymalBuffers(C.Structure):
 
 
 class AnymalResetIO(C.Structure):
-    _fields_ = [
+    _fields_ = ([
         ("u_dof_offset", _fp), ("u_dof_vel", _fp), ("u_xy", _fp), ("u_cmd", _fp), ("noise_u", _fp), ("reset_mask", _fp),
         ("seed", C.c_uint64), ("step", C.c_uint64),
         ("env_ids", _fp), ("count", _fp), ("base_pos_out", _fp), ("base_quat_out", _fp), ("base_vel_out", _fp),
         ("dof_pos_out", _fp), ("dof_vel_out", _fp),
-    ]
+    ]) + [("step_ptr", _fp)]
 
 
 class AnymalFlatParams(C.Structure):
@@ -175,9 +176,9 @@ class AnymalFlatBuffers(C.Structure):
 
 
 class AnymalFlatResetIO(C.Structure):
-    _fields_ = [("initial_root_pos", _fp), ("initial_root_rot", _fp), ("u_vel", _fp), ("u_cmd", _fp), ("seed", C.c_uint64),
+    _fields_ = ([("initial_root_pos", _fp), ("initial_root_rot", _fp), ("u_vel", _fp), ("u_cmd", _fp), ("seed", C.c_uint64),
                 ("step", C.c_uint64), ("env_ids", _fp), ("count", _fp), ("dof_pos_out", _fp), ("dof_vel_out", _fp),
-                ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp)]
+                ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp)]) + [("step_ptr", _fp)]
 
 
 class QuadcopterParams(C.Structure):
@@ -195,9 +196,9 @@ class QuadcopterBuffers(C.Structure):
 
 
 class QuadcopterResetIO(C.Structure):
-    _fields_ = [("initial_root_pos", _fp), ("initial_root_rot", _fp), ("u_dof", _fp), ("u_xyz", _fp), ("seed", C.c_uint64),
+    _fields_ = ([("initial_root_pos", _fp), ("initial_root_rot", _fp), ("u_dof", _fp), ("u_xyz", _fp), ("seed", C.c_uint64),
                 ("step", C.c_uint64), ("env_ids", _fp), ("count", _fp), ("dof_pos_out", _fp), ("dof_vel_out", _fp),
-                ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp)]
+                ("root_pos_out", _fp), ("root_rot_out", _fp), ("root_vel_out", _fp)]) + [("step_ptr", _fp)]
 
 
 class BallBalanceParams(C.Structure):
@@ -214,10 +215,10 @@ class BallBalanceBuffers(C.Structure):
 
 
 class BallBalanceResetIO(C.Structure):
-    _fields_ = [(n, _fp) for n in ("initial_ball_pos", "initial_bot_pos", "initial_bot_rot", "initial_bot_velocities",
+    _fields_ = ([(n, _fp) for n in ("initial_ball_pos", "initial_bot_pos", "initial_bot_rot", "initial_bot_velocities",
                                    "initial_dof_positions", "u")] + [("seed", C.c_uint64), ("step", C.c_uint64)] + [
         (n, _fp) for n in ("env_ids", "count", "ball_pos_out", "ball_rot_out", "ball_vel_out", "bot_pos_out", "bot_rot_out",
-                           "bot_vel_out", "dof_pos_out")]
+                           "bot_vel_out", "dof_pos_out")]) + [("step_ptr", _fp)]
 
 
 class IngenuityParams(C.Structure):
@@ -235,10 +236,10 @@ class IngenuityBuffers(C.Structure):
 
 
 class IngenuityResetIO(C.Structure):
-    _fields_ = [(n, _fp) for n in ("initial_root_pos", "initial_root_rot", "initial_ball_rot", "env_pos", "u_reset", "u_target")] + [
+    _fields_ = ([(n, _fp) for n in ("initial_root_pos", "initial_root_rot", "initial_ball_rot", "env_pos", "u_reset", "u_target")] + [
         ("seed", C.c_uint64), ("step", C.c_uint64)] + [
         (n, _fp) for n in ("env_ids", "count", "dof_pos_out", "dof_vel_out", "root_pos_out", "root_rot_out", "root_vel_out",
-                           "target_ids", "target_count", "ball_pos_out", "ball_rot_out")]
+                           "target_ids", "target_count", "ball_pos_out", "ball_rot_out")]) + [("step_ptr", _fp)]
 
 
 class FrankaCabinetParams(C.Structure):
@@ -263,9 +264,9 @@ class FrankaCabinetBuffers(C.Structure):
 
 
 class FrankaCabinetResetIO(C.Structure):
-    _fields_ = [("u_dof", _fp), ("default_prop_pos", _fp), ("default_prop_rot", _fp), ("seed", C.c_uint64), ("step", C.c_uint64)] + [
+    _fields_ = ([("u_dof", _fp), ("default_prop_pos", _fp), ("default_prop_rot", _fp), ("seed", C.c_uint64), ("step", C.c_uint64)] + [
         (n, _fp) for n in ("env_ids", "count", "dof_pos_out", "dof_vel_out", "cabinet_dof_pos_out", "cabinet_dof_vel_out", "prop_ids",
-                           "prop_count", "prop_pos_out", "prop_rot_out")]
+                           "prop_count", "prop_pos_out", "prop_rot_out")]) + [("step_ptr", _fp)]
 
 
 class NewhandCabinetParams(C.Structure):

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
   // dense lanes: thread j takes the group's j-th flagged env
   if (tid < cnt) {
     const int64_t i = g * GROUP + s_list[tid];
-    const u4 c{(uint32_t)i, 3u, (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};  // draws 12, 13, 14: x, y, yaw
+    const u4 c{(uint32_t)i, 3u, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};  // draws 12, 13, 14: x, y, yaw
     const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
     const float u3[3] = {u01(x.x), u01(x.y), u01(x.z)};
     anymal_flat_reset_head(a, i, (int64_t)k0 + tid, u3);
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
     float ct[4];
     if (lr >= 0) {  // reset row (:199-203, :230-231)
       const int64_t i = g * GROUP + il;
-      const u4 c{(uint32_t)i, (uint32_t)(j0 >> 2), (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};  // draws j0 .. j0+3
+      const u4 c{(uint32_t)i, (uint32_t)(j0 >> 2), (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};  // draws j0 .. j0+3
       const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
       const int64_t row = ((int64_t)k0 + lr) * FD + j0;
       *reinterpret_cast<float4*>(a.r.dof_vel_out + row) =
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256) void anymal_flat_reset_idx_kernel(const Anymal
   } else {
 #pragma unroll
     for (int blk = 0; blk < 4; ++blk) {
-      const u4 c{(uint32_t)i, (uint32_t)blk, (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
+      const u4 c{(uint32_t)i, (uint32_t)blk, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};
       const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
       u[4 * blk] = u01(x.x); u[4 * blk + 1] = u01(x.y); u[4 * blk + 2] = u01(x.z); u[4 * blk + 3] = u01(x.w);
     }

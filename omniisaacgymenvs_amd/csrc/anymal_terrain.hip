@@ -155,13 +155,13 @@ __device__ __forceinline__ float div_by_const(float x, float h, float inv) {
 __device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // uniform noise of four consecutive observation columns starting at flat float offset `off` (:438-439)
-__device__ __forceinline__ void anymal_noise4(const oige_anymal_reset_io& r, int64_t off, float (&uu)[4]) {
+__device__ __forceinline__ void anymal_noise4(const oige_anymal_reset_io& r, uint64_t step, int64_t off, float (&uu)[4]) {
   if (r.noise_u) {
     const float4 t4 = *reinterpret_cast<const float4*>(r.noise_u + off);
     uu[0] = t4.x; uu[1] = t4.y; uu[2] = t4.z; uu[3] = t4.w;
   } else {
     const int64_t gf = off / 4;
-    const u4 cc{(uint32_t)gf, (uint32_t)(gf >> 32) | (3u << 16), (uint32_t)r.step, (uint32_t)(r.step >> 32)};
+    const u4 cc{(uint32_t)gf, (uint32_t)(gf >> 32) | (3u << 16), (uint32_t)step, (uint32_t)(step >> 32)};
     const u4 x = philox4x32_10(cc, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
     uu[0] = u01(x.x); uu[1] = u01(x.y); uu[2] = u01(x.z); uu[3] = u01(x.w);
   }
@@ -173,6 +173,7 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
   float* s_ns = lds + TILE * ARW;            // 48: noise_scale_vec (:157-171) by LDS column (head 0:36, actions 36:48)
   const oige_anymal_params& p = a.p;
   const int tid = threadIdx.x;               // one wavefront per tile
+  const uint64_t noise_step = step_of(a.r);  // read once: by value, or the device counter of a replayed graph
   const int64_t env0 = t * TILE;
   const int64_t T = num_tiles(a.n);
   float* pose_out = a.b.reduce_workspace + pose_offset(T) + env0 * APOSE;
@@ -332,7 +333,7 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
             u[0] = a.r.u_cmd[k * 3 + 2]; u[1] = u[2] = u[3] = 0.f;
           }
         } else {
-          const u4 c{(uint32_t)env, (uint32_t)blk | (1u << 16), (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
+          const u4 c{(uint32_t)env, (uint32_t)blk | (1u << 16), (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};
           const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
           u[0] = u01(x.x); u[1] = u01(x.y); u[2] = u01(x.z); u[3] = u01(x.w);
         }
@@ -465,7 +466,7 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
 #ifndef OIGE_EXP_NO_NOISE
       if (p.add_noise) {
         float uu[4];
-        anymal_noise4(a.r, off, uu);
+        anymal_noise4(a.r, noise_step, off, uu);
         const float4 sc = lds4(s_ns + lcol);
         v.x = v.x + (2.0f * uu[0] - 1.0f) * sc.x;
         v.y = v.y + (2.0f * uu[1] - 1.0f) * sc.y;
@@ -518,6 +519,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
                                                  float* __restrict__ s_strip, int64_t t, int nv) {
   const oige_anymal_params& p = a.p;
   const int tid = threadIdx.x;
+  const uint64_t noise_step = step_of(a.r);
   const int64_t env0 = t * TILE;
   const float* pose_in = a.b.reduce_workspace + pose_offset(num_tiles(a.n)) + env0 * APOSE;
   if (tid < AP) {  // meshgrid(x, y, indexing='ij') flattened: k = ix * 10 + iy
@@ -616,7 +618,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
 #ifndef OIGE_EXP_NO_NOISE
         if (p.add_noise) {
           float uu[4];
-          anymal_noise4(a.r, off, uu);
+          anymal_noise4(a.r, noise_step, off, uu);
           v.x = v.x + (2.0f * uu[0] - 1.0f) * nscale;
           v.y = v.y + (2.0f * uu[1] - 1.0f) * nscale;
           v.z = v.z + (2.0f * uu[2] - 1.0f) * nscale;

@@ -158,8 +158,8 @@ __device__ __forceinline__ void ball_reset_env(const BallPre& a, int64_t i, int6
 }
 
 __device__ __forceinline__ void ball_draw(const BallPre& a, int64_t i, float (&u)[5]) {
-  const u4 c0{(uint32_t)i, 0u, (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
-  const u4 c1{(uint32_t)i, 1u, (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
+  const u4 c0{(uint32_t)i, 0u, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};
+  const u4 c1{(uint32_t)i, 1u, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};
   const u4 x = philox4x32_10(c0, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
   const u4 y = philox4x32_10(c1, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
   u[0] = u01(x.x); u[1] = u01(x.y); u[2] = u01(x.z); u[3] = u01(x.w); u[4] = u01(y.x);

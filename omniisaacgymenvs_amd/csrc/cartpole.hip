@@ -79,7 +79,7 @@ __device__ __forceinline__ void cartpole_reset_env(const CartPre& a, int64_t i, 
 #pragma unroll
     for (int q = 0; q < 4; ++q) u[q] = a.r.u[q * n_rows + k];
   } else {
-    const u4 c{(uint32_t)i, 0u, (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
+    const u4 c{(uint32_t)i, 0u, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};
     const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
     u[0] = u01(x.x); u[1] = u01(x.y); u[2] = u01(x.z); u[3] = u01(x.w);
   }

@@ -188,7 +188,7 @@ struct FrankaPre {
 __device__ __forceinline__ void franka_draws(const FrankaPre& a, int64_t i, float (&u)[FMAX]) {
 #pragma unroll
   for (uint32_t blk = 0; blk < 3; ++blk) {
-    const u4 c{(uint32_t)i, blk, (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
+    const u4 c{(uint32_t)i, blk, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};
     const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
     u[blk * 4 + 0] = u01(x.x);
     if (blk < 2) { u[blk * 4 + 1] = u01(x.y); u[blk * 4 + 2] = u01(x.z); u[blk * 4 + 3] = u01(x.w); }

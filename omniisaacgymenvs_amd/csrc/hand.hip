@@ -632,7 +632,7 @@ template <int COUNT>
 __device__ __forceinline__ void hand_draw(const oige_hand_reset_io& r, int64_t i, uint32_t stream, float (&out)[COUNT]) {
 #pragma unroll
   for (int blk = 0; blk < (COUNT + 3) / 4; ++blk) {
-    const u4 c{(uint32_t)i, (uint32_t)blk | (stream << 16), (uint32_t)r.step, (uint32_t)(r.step >> 32)};
+    const u4 c{(uint32_t)i, (uint32_t)blk | (stream << 16), (uint32_t)step_of(r), (uint32_t)(step_of(r) >> 32)};
     const u4 x = philox4x32_10(c, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
     const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -745,8 +745,8 @@ __device__ __forceinline__ void hand_reset_env_head(const HandPre& a, int64_t i,
 // draws idx0 .. idx0+3 of env i's U(-1,1) table on `stream`, idx0 = 4m + 1: words 1..3 of block m, word 0 of block m+1
 __device__ __forceinline__ void hand_draw4_at(const oige_hand_reset_io& r, int64_t i, uint32_t stream, int idx0, float (&out)[4]) {
   const uint32_t m = (uint32_t)(idx0 >> 2);
-  const u4 c0{(uint32_t)i, m | (stream << 16), (uint32_t)r.step, (uint32_t)(r.step >> 32)};
-  const u4 c1{(uint32_t)i, (m + 1u) | (stream << 16), (uint32_t)r.step, (uint32_t)(r.step >> 32)};
+  const u4 c0{(uint32_t)i, m | (stream << 16), (uint32_t)step_of(r), (uint32_t)(step_of(r) >> 32)};
+  const u4 c1{(uint32_t)i, (m + 1u) | (stream << 16), (uint32_t)step_of(r), (uint32_t)(step_of(r) >> 32)};
   const u4 x0 = philox4x32_10(c0, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
   const u4 x1 = philox4x32_10(c1, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
   out[0] = um11(x0.y); out[1] = um11(x0.z); out[2] = um11(x0.w); out[3] = um11(x1.x);

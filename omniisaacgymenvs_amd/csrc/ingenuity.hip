@@ -118,7 +118,7 @@ __global__ __launch_bounds__(GROUP) void ingenuity_count_kernel(const IngPre a) 
 }
 
 __device__ __forceinline__ u4 ing_block(const IngPre& a, int64_t i, uint32_t blk) {
-  const u4 c{(uint32_t)i, blk, (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
+  const u4 c{(uint32_t)i, blk, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};
   return philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
 }
 

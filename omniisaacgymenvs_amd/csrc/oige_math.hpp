@@ -165,6 +165,10 @@ OIGE_DEV u4 philox4x32_10(u4 c, uint32_t k0, uint32_t k1) {
   return c;
 }
 // top 24 bits -> [0,1) exactly representable in fp32 (same grid torch.rand draws from)
+// the Philox step counter of a reset_io block: by value, or from the device scalar a replayed HIP graph advances
+template <class R>
+OIGE_DEV uint64_t step_of(const R& r) { return r.step_ptr ? *r.step_ptr : r.step; }
+
 OIGE_DEV float u01(const uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
 
 }  // namespace oige

@@ -115,7 +115,7 @@ struct QuadPre {
 
 // U[0,1) draws of env i (in-kernel path): block 0, 1 -> the 8 DOF draws, block 2 -> x, y, z
 __device__ __forceinline__ u4 quad_block(const QuadPre& a, int64_t i, uint32_t blk) {
-  const u4 c{(uint32_t)i, blk, (uint32_t)a.r.step, (uint32_t)(a.r.step >> 32)};
+  const u4 c{(uint32_t)i, blk, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};
   return philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
 }
 

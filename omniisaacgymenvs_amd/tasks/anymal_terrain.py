@@ -52,6 +52,8 @@ class SyntheticAnymalView(SyntheticArticulationView):
 
 
 class AnymalTerrainTask(RLTask):
+    graph_capturable = ("the step has host-side branches that change from step to step (push_robots every push_interval "
+                        "steps, the curriculum read-backs): a captured graph would freeze one of them")
     def __init__(self, name, sim_config, env, offset=None) -> None:
         self.height_samples = None
         self.custom_origins = False

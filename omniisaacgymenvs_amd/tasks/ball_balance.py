@@ -175,6 +175,7 @@ class BallBalanceTask(RLTask):
             r.u = u.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
         r.step = self._step_count
+        r.step_ptr = self._graph_step_ptr()
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.ball_pos_out, r.ball_rot_out, r.ball_vel_out = o["ball_pos"].data_ptr(), o["ball_rot"].data_ptr(), o["ball_vel"].data_ptr()
@@ -200,7 +201,7 @@ class BallBalanceTask(RLTask):
         n = self._num_envs
         actions = actions.to(self.device)
         _lib.require_device_tensor(actions, torch.float32, (n, 3), "actions")
-        self._step_count += 1
+        self._advance_step_counter()
         flags, ids = 0, None
         if not self.sync_free:
             o = self._reset_out
@@ -209,7 +210,7 @@ class BallBalanceTask(RLTask):
             if num > 0:
                 ids = o["env_ids"][:num].clone()
                 self.reset_idx(ids)
-        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key:
+        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key and not self._capturing:
             flags |= _lib.PRE_COUNTS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS

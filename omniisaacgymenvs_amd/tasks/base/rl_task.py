@@ -114,6 +114,70 @@ class RLTask:
     def default_zero_env_path(self) -> str:
         return f"{self.default_base_env_path}/env_0"
 
+    # ------------------------------------------------------------------ HIP-graph step (launch-bound sizes)
+    graph_capturable = True   # tasks whose step has host-side branches that change from step to step set this to a reason string
+    _capturing = False
+    _step_dev = None
+
+    def _graph_step_ptr(self):
+        """``reset_io.step_ptr``: the device-side Philox step counter while a step is being captured, else NULL."""
+        return self._step_dev.data_ptr() if self._capturing else None
+
+    def _advance_step_counter(self) -> None:
+        self._step_count = getattr(self, "_step_count", 0) + 1
+        if self._step_dev is not None and not self._capturing:
+            self._step_dev += 1  # an eager step between replays: keep the captured graph's counter in step
+
+    def capture_step(self, actions: torch.Tensor) -> None:
+        """Capture ``pre_physics_step(actions); post_physics_step()`` into one HIP graph (torch.cuda.CUDAGraph on ROCm).
+
+        At the reference's own sizes (4096 envs) the step is bound by launches and Python marshalling, not by the GPU; a
+        replay is one graph launch.  ``actions`` is the static input buffer: refill it in place (``actions.copy_(...)``)
+        before each ``replay_step()``.  The sync-free, fused path is required; the view setters must consume
+        ``(values, indices, count)`` on the device (synthetic views: ``apply_resets="device"`` or ``False``).  By-value kernel
+        arguments are baked into the graph, so the Philox step counter moves to a device scalar that the graph itself
+        advances (``reset_io.step_ptr``), ``OIGE_PRE_COUNTS_VALID`` is never baked in, and scalars edited on the task afterwards
+        (``task.heading_weight = ...``) or rebound buffers need a new capture.  One eager step runs first as warm-up (lazy
+        code-object loads are illegal during capture): this call advances the task by one step and leaves the second one
+        captured, not executed."""
+        if self.graph_capturable is not True:
+            raise NotImplementedError(f"{type(self).__name__}.capture_step: {self.graph_capturable}")
+        if not (getattr(self, "sync_free", False) and getattr(self, "fused", False)):
+            raise RuntimeError("capture_step needs the sync-free fused path (task.sync_free = task.fused = True)")
+        if not self.world.is_playing():
+            raise RuntimeError("capture_step: the world is not playing")
+        from ... import _lib
+
+        dev = self.obs_buf.device
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, self.num_actions), "actions")
+        self._step_dev = torch.full((1,), getattr(self, "_step_count", 0), dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        self._capturing = True
+        try:
+            with torch.cuda.stream(side):  # warm-up: one real step on the side stream
+                self._step_dev += 1
+                self.pre_physics_step(actions)
+                self.post_physics_step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            count0 = getattr(self, "_step_count", 0)
+            with torch.cuda.graph(graph, stream=side):
+                self._step_dev += 1
+                self.pre_physics_step(actions)
+                self.post_physics_step()
+            self._step_count = count0  # the captured step has not run yet
+        finally:
+            self._capturing = False
+        self._graph, self._graph_actions = graph, actions
+
+    def replay_step(self):
+        """One captured step; returns what ``post_physics_step`` returns.  ``task._graph_actions`` holds the actions."""
+        self._graph.replay()
+        self._step_count = getattr(self, "_step_count", 0) + 1
+        self._counts_key = None
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
     # ------------------------------------------------------------------ RL interface
     def reset(self) -> None:
         """Flag every env for reset (:274-276; rebinds, as the reference does)."""

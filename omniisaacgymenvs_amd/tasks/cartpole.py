@@ -111,6 +111,7 @@ class CartpoleTask(RLTask):
             r.u = u.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
         r.step = self._step_count
+        r.step_ptr = self._graph_step_ptr()
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
@@ -122,7 +123,7 @@ class CartpoleTask(RLTask):
         n = self._num_envs
         actions = actions.to(self._device)
         _lib.require_device_tensor(actions, torch.float32, (n, 1), "actions")
-        self._step_count += 1
+        self._advance_step_counter()
         flags = 0
         o = self._reset_out
         if not self.sync_free:
@@ -130,7 +131,7 @@ class CartpoleTask(RLTask):
             num = int(o["count"].item())
             if num > 0:
                 self.reset_idx(o["env_ids"][:num].clone())
-        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key:
+        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key and not self._capturing:
             flags |= _lib.PRE_COUNTS_VALID
         p, b, r = self._params(), self._buffers(), self._reset_io()
         rc = _lib.load().oige_cartpole_pre_physics(

@@ -297,6 +297,7 @@ class FrankaCabinetTask(RLTask):
             r.default_prop_pos, r.default_prop_rot = self.default_prop_pos.data_ptr(), self.default_prop_rot.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
         r.step = self._step_count
+        r.step_ptr = self._graph_step_ptr()
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
         r.cabinet_dof_pos_out, r.cabinet_dof_vel_out = o["cabinet_dof_pos"].data_ptr(), o["cabinet_dof_vel"].data_ptr()
@@ -326,7 +327,7 @@ class FrankaCabinetTask(RLTask):
         n = self._num_envs
         actions = actions.to(self._device)
         _lib.require_device_tensor(actions, torch.float32, (n, self.NUM_DOFS), "actions")
-        self._step_count += 1
+        self._advance_step_counter()
         flags = 0
         if not self.sync_free:
             o = self._reset_out
@@ -334,7 +335,7 @@ class FrankaCabinetTask(RLTask):
             num = int(o["count"].item())
             if num > 0:
                 self.reset_idx(o["env_ids"][:num].clone())
-        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key:
+        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key and not self._capturing:
             flags |= _lib.PRE_COUNTS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS

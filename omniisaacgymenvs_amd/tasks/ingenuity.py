@@ -162,6 +162,7 @@ class IngenuityTask(RLTask):
             r.u_target = u_target.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
         r.step = self._step_count
+        r.step_ptr = self._graph_step_ptr()
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
@@ -194,7 +195,7 @@ class IngenuityTask(RLTask):
         n = self._num_envs
         actions = actions.to(self._device)
         _lib.require_device_tensor(actions, torch.float32, (n, 6), "actions")
-        self._step_count += 1
+        self._advance_step_counter()
         flags, ids = 0, None
         if not self.sync_free:
             # the reference's flow: host-visible id lists, torch-drawn noise (:153-160)

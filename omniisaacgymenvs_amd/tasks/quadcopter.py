@@ -93,14 +93,15 @@ class QuadcopterTask(RLTask):
             "root_pos": torch.zeros((n, 3), **f), "root_rot": torch.zeros((n, 4), **f), "root_vel": torch.zeros((n, 6), **f),
         }
         self._counts_key = None
-        self._host_consts = {"lower": self.dof_lower_limits.tolist(), "upper": self.dof_upper_limits.tolist()}
+        self._host_consts = {"lower": self.dof_lower_limits.tolist(), "upper": self.dof_upper_limits.tolist(),
+                             "max_thrust": float(self.thrust_upper_limits[0])}
 
     # ------------------------------------------------------------------ C-ABI argument blocks
     def _params(self) -> _lib.QuadcopterParams:
         p = _lib.QuadcopterParams()
         p.dof_rate = self.dt * (8 * math.pi)     # self.dt * dof_action_speed_scale (:153-154), a Python double product
         p.thrust_rate = self.dt * 100            # :159-160
-        p.max_thrust = float(self.thrust_upper_limits[0]) if self._num_envs >= 0 else 2.0
+        p.max_thrust = self._host_consts["max_thrust"]  # read back once in post_reset: a per-step float(tensor) is a device sync
         p.clip_actions = float(min(self.clip_actions, 3.0e38))
         p.max_episode_length = int(self._max_episode_length)
         for i in range(8):
@@ -171,6 +172,7 @@ class QuadcopterTask(RLTask):
             r.u_dof, r.u_xyz = u_dof.data_ptr(), u_xyz.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
         r.step = self._step_count
+        r.step_ptr = self._graph_step_ptr()
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
@@ -194,7 +196,7 @@ class QuadcopterTask(RLTask):
         n = self._num_envs
         actions = actions.to(self._device)
         _lib.require_device_tensor(actions, torch.float32, (n, 12), "actions")
-        self._step_count += 1
+        self._advance_step_counter()
         flags = 0
         if not self.sync_free:
             o = self._reset_out
@@ -203,7 +205,7 @@ class QuadcopterTask(RLTask):
             ids = o["env_ids"][:num].clone()
             if num > 0:
                 self.reset_idx(ids)
-        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key:
+        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key and not self._capturing:
             flags |= _lib.PRE_COUNTS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS

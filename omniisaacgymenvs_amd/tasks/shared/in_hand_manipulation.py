@@ -300,6 +300,7 @@ class InHandManipulationTask(RLTask):
             r.u_reset, r.u_reset_goal = u_reset.data_ptr(), u_reset_goal.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
         r.step = self._step_count
+        r.step_ptr = self._graph_step_ptr()
         o = self._reset_out
         r.goal_ids, r.goal_count = o["goal_ids"].data_ptr(), o["goal_count"].data_ptr()
         r.goal_world_pos_out, r.goal_rot_out = o["goal_world_pos"].data_ptr(), o["goal_rot"].data_ptr()
@@ -340,7 +341,7 @@ class InHandManipulationTask(RLTask):
         n = self._num_envs
         actions = actions.to(self.device)
         _lib.require_device_tensor(actions, torch.float32, (n, self._num_actions), "actions")
-        self._step_count += 1
+        self._advance_step_counter()
         flags = 0
         o = self._reset_out
         if not self.sync_free:
@@ -356,7 +357,7 @@ class InHandManipulationTask(RLTask):
         else:
             key = (self.reset_buf.data_ptr(), self.reset_buf._version,
                    self.reset_goal_buf.data_ptr(), self.reset_goal_buf._version)
-            if key == self._counts_key:
+            if key == self._counts_key and not self._capturing:
                 flags |= _lib.PRE_COUNTS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS  # the wrapper's clamp (vec_env_rlgames.py:77), folded into the kernel

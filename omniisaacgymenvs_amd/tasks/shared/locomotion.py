@@ -201,58 +201,13 @@ class LocomotionTask(RLTask):
             r.u_pos, r.u_vel = u_pos.data_ptr(), u_vel.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
         r.step = self._step_count
-        if getattr(self, "_capturing", False):
-            r.step_ptr = self._step_dev.data_ptr()  # graph mode: the Philox step counter lives on the device
+        r.step_ptr = self._graph_step_ptr()  # graph capture: the Philox step counter lives on the device
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
         r.root_pos_out, r.root_rot_out, r.root_vel_out = (
             o["root_pos"].data_ptr(), o["root_rot"].data_ptr(), o["root_vel"].data_ptr())
         return r
-
-    # ------------------------------------------------------------------ HIP-graph step (launch-bound sizes)
-    def capture_step(self, actions: torch.Tensor) -> None:
-        """Capture ``pre_physics_step(actions); post_physics_step()`` into one HIP graph (torch.cuda.CUDAGraph on ROCm).
-
-        At the reference's own sizes (4096 envs) the step is bound by launches and Python marshalling, not by the GPU; a
-        replay is one graph launch.  ``actions`` is the static input buffer: refill it in place (``actions.copy_(...)``)
-        before each ``replay_step()``.  The sync-free, fused path is required; the view setters must consume
-        ``(values, indices, count)`` on the device (synthetic views: ``apply_resets="device"`` or ``False``).  By-value kernel
-        arguments are baked into the graph, so the Philox step counter moves to a device scalar that the graph itself
-        advances, scalars edited on the task afterwards (``task.heading_weight = ...``) need a new capture, and so do rebound
-        buffers.  One eager step runs first as warm-up (lazy code-object loads are illegal during capture): this call advances
-        the task by one step and leaves the second one captured, not executed."""
-        if not (self.sync_free and self.fused):
-            raise RuntimeError("capture_step needs the sync-free fused path (task.sync_free = task.fused = True)")
-        if not self.world.is_playing():
-            raise RuntimeError("capture_step: the world is not playing")
-        dev = self.obs_buf.device
-        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, self._robots.num_dof), "actions")
-        self._step_dev = torch.full((1,), self._step_count, dtype=torch.int64, device=dev)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):  # warm-up: one real step on the side stream
-            self._step_dev += 1
-            self._capturing = True
-            self.pre_physics_step(actions)
-            self.post_physics_step()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        count0 = self._step_count
-        with torch.cuda.graph(graph, stream=side):
-            self._step_dev += 1
-            self.pre_physics_step(actions)
-            self.post_physics_step()
-        self._step_count = count0  # the captured step has not run yet
-        self._capturing = False
-        self._graph, self._graph_actions = graph, actions
-
-    def replay_step(self):
-        """One captured step; returns what ``post_physics_step`` returns.  ``task._graph_actions`` holds the actions."""
-        self._graph.replay()
-        self._step_count += 1
-        self._counts_key = None
-        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def _apply_reset_writes(self, n=None) -> None:
         """Hand the compacted rows to the view setters (:145-149).  ``n`` None -> device count."""
@@ -274,9 +229,7 @@ class LocomotionTask(RLTask):
         n, d = self._num_envs, self._robots.num_dof
         actions = actions.to(self._device)
         _lib.require_device_tensor(actions, torch.float32, (n, d), "actions")
-        self._step_count += 1
-        if getattr(self, "_step_dev", None) is not None and not getattr(self, "_capturing", False):
-            self._step_dev += 1  # an eager step between replays: keep the captured graph's counter in step
+        self._advance_step_counter()
         flags = 0
         if not self.sync_free:
             # the reference's flow: host-visible id list, torch-drawn noise (:121-123)
@@ -285,7 +238,7 @@ class LocomotionTask(RLTask):
             num = int(o["count"].item())
             if num > 0:
                 self.reset_idx(o["env_ids"][:num].clone())
-        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key and not getattr(self, "_capturing", False):
+        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key and not self._capturing:
             flags |= _lib.PRE_COUNTS_VALID  # the DONE stage's tile counts still describe reset_buf (never baked into a graph)
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS  # the wrapper's clamp (vec_env_rlgames.py:77), folded into the kernel

@@ -1,91 +1,119 @@
-"""-m gpu: LocomotionTask.capture_step / replay_step (one HIP graph per step, for launch-bound sizes) is bit-identical to the
-eager sync-free step -- same kernels, same Philox keys (the step counter moves to a device scalar) -- and cheaper on the host."""
+"""-m gpu: RLTask.capture_step / replay_step (one HIP graph per step, for launch-bound sizes) is bit-identical to the eager
+sync-free step -- same kernels, same Philox keys (the step counter moves to a device scalar, reset_io.step_ptr) -- and cheaper
+on the host.  Every tensor the task and its views hold is compared after every step."""
 import json
 import os
+import sys
 import time
 
 import pytest
 import torch
 
-from helpers import assert_equal, make_task
-from omniisaacgymenvs_amd.sim import workloads
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402  (the adapters build a task with a loaded synthetic state)
+from helpers import assert_equal  # noqa: E402
 
 pytestmark = pytest.mark.gpu
+CASES = [("Ant", 4096), ("Ant", 300), ("Humanoid", 1000), ("ShadowHand", 1000), ("AllegroHand", 700), ("Anymal", 1000), ("Quadcopter", 900),
+         ("BallBalance", 900), ("Ingenuity", 900), ("Crazyflie", 900), ("FrankaCabinet", 900), ("TomoSPCCabinet", 500),
+         ("TomoDJnewhandTendonCabinet", 500)]
 
 
-def _task(name, n, mode):
+def _views(task):
+    out = {}
+    for k, v in vars(task).items():
+        if hasattr(v, "apply_resets"):
+            out[k] = v
+            for kk, vv in vars(v).items():
+                if hasattr(vv, "apply_resets"):
+                    out[f"{k}.{kk}"] = vv
+    return out
+
+
+def _build(name, n, mode):
     torch.manual_seed(7)
-    env, task = make_task(name, n)
-    z = (0.2, 0.9) if name == "Ant" else (0.5, 1.5)
-    st = workloads.locomotion_state(n, task.dof_limits_lower, task.dof_limits_upper, task._num_sensors, device=task.device, seed=11, z_range=z)
-    workloads.load_locomotion_state(task, st)
-    task._robots.apply_resets = mode
-    return task, st
+    b = bench.ADAPTERS[name](name, n, "cuda:0", 11)
+    for v in _views(b.task).values():
+        v.apply_resets = mode
+    return b
 
 
-def _snapshot(task):
-    r = task._robots
-    return {k: v.clone() for k, v in dict(obs=task.obs_buf, rew=task.rew_buf, reset=task.reset_buf, progress=task.progress_buf,
-                                          potentials=task.potentials, prev=task.prev_potentials, actions=task.actions, forces=task._forces,
-                                          q=r.joint_positions, qd=r.joint_velocities, pos=r.positions, rot=r.orientations,
-                                          vel=r.velocities, ids=task._reset_out["env_ids"], count=task._reset_out["count"]).items()}
+def _tensors(task):
+    out = {}
+    for k, v in vars(task).items():
+        if isinstance(v, torch.Tensor) and k not in ("_step_dev", "_graph_actions", "_noise4"):
+            out[k] = v
+        elif isinstance(v, dict) and k == "_reset_out":
+            out.update({f"_reset_out.{kk}": vv for kk, vv in v.items() if "count" in kk})
+    for name, view in _views(task).items():
+        for k, v in vars(view).items():
+            if isinstance(v, torch.Tensor):
+                out[f"{name}.{k}"] = v
+    return out
 
 
-@pytest.mark.parametrize("name,n", [("Ant", 4096), ("Ant", 300), ("Humanoid", 1000)])
+@pytest.mark.parametrize("name,n", CASES)
 def test_graph_replay_equals_eager_steps(name, n):
-    eager, st = _task(name, n, True)        # host-applied reset rows (reads count)
-    graph, _ = _task(name, n, "device")     # device-applied reset rows (no read-back: legal under capture)
+    eager, graph = _build(name, n, True), _build(name, n, "device")   # host-applied vs device-applied reset rows
     g = torch.Generator().manual_seed(3)
-    acts = [(torch.rand(n, eager._robots.num_dof, generator=g) * 2 - 1).to(eager.device) for _ in range(6)]
+    A = eager.task.num_actions
+    acts = [(torch.rand(n, A, generator=g) * 2 - 1).to("cuda:0") for _ in range(6)]
     static = acts[0].clone()
-    graph.capture_step(static)              # runs step 0 eagerly (warm-up), captures the step
-    eager.pre_physics_step(acts[0])
-    eager.post_physics_step()
+    te, tg = eager.task, graph.task
+    torch.manual_seed(99)
+    tg.capture_step(static)              # runs step 0 eagerly (warm-up), captures the step
+    torch.manual_seed(99)
+    te.pre_physics_step(acts[0])
+    te.post_physics_step()
     total_resets = 0
     for a in acts[1:]:
         static.copy_(a)
-        obs, rew, reset, _ = graph.replay_step()
-        eager.pre_physics_step(a)
-        eager.post_physics_step()
+        torch.manual_seed(5)             # Crazyflie draws its thrust noise with torch: same generator state on both sides
+        obs, rew, reset, _ = tg.replay_step()
+        torch.manual_seed(5)
+        te.pre_physics_step(a)
+        te.post_physics_step()
         torch.cuda.synchronize()
-        A, B = _snapshot(eager), _snapshot(graph)
-        k = int(A["count"])
-        total_resets += k
-        assert int(B["count"]) == k
-        for key in A:
-            if key == "ids":
-                assert_equal(B[key][:k], A[key][:k], key)
-            else:
-                assert_equal(B[key], A[key], key)
-        assert obs.data_ptr() == graph.obs_buf.data_ptr()
-    assert total_resets > 0 and graph._step_count == eager._step_count
+        total_resets += int(te._reset_out["count"])
+        A_, B_ = _tensors(te), _tensors(tg)
+        assert set(A_) == set(B_)
+        for key in A_:
+            assert_equal(B_[key], A_[key], key)
+        assert obs.data_ptr() == tg.obs_buf.data_ptr()
+    assert total_resets > 0
+    if hasattr(te, "_step_count"):   # tasks with in-kernel Philox draws (Crazyflie has none)
+        assert tg._step_count == te._step_count
     # an eager step in between keeps the device counter in step with the host's
-    graph.pre_physics_step(acts[1]); graph.post_physics_step()
-    eager.pre_physics_step(acts[1]); eager.post_physics_step()
+    torch.manual_seed(6); tg.pre_physics_step(acts[1]); tg.post_physics_step()
+    torch.manual_seed(6); te.pre_physics_step(acts[1]); te.post_physics_step()
     static.copy_(acts[2])
-    graph.replay_step()
-    eager.pre_physics_step(acts[2]); eager.post_physics_step()
+    torch.manual_seed(8); tg.replay_step()
+    torch.manual_seed(8); te.pre_physics_step(acts[2]); te.post_physics_step()
     torch.cuda.synchronize()
-    assert_equal(graph.obs_buf, eager.obs_buf, "obs after a mixed eager/replay sequence")
-    assert_equal(graph._robots.joint_positions, eager._robots.joint_positions, "joint positions after a mixed sequence")
+    assert_equal(tg.obs_buf, te.obs_buf, "obs after a mixed eager/replay sequence")
+    assert_equal(tg.reset_buf, te.reset_buf, "reset_buf after a mixed eager/replay sequence")
 
 
-def test_capture_needs_the_sync_free_path():
-    task, st = _task("Ant", 64, "device")
-    task.sync_free = False
+def test_capture_needs_the_sync_free_path_and_a_capturable_task():
+    b = _build("Ant", 64, "device")
+    b.task.sync_free = False
     with pytest.raises(RuntimeError, match="sync-free"):
-        task.capture_step(st["actions"])
+        b.task.capture_step(b.actions)
+    t = _build("AnymalTerrain", 64, False)
+    with pytest.raises(NotImplementedError, match="host-side branches"):
+        t.task.capture_step(t.actions)
 
 
 def test_replay_cost_at_the_reference_size():
-    """Measurement: wall time per step at 4096 envs (the reference's Ant default), eager mirror vs graph replay."""
+    """Measurement: wall time per step at 4096 envs (the reference's default size), eager mirror vs graph replay; the reset rows
+    are handed over and dropped (the task math alone, as bench.py measures it)."""
     n, steps = 4096, 2000
     out = {}
-    # views: False = the reset rows are handed over and dropped (the task math alone, as bench.py measures it);
-    # "device" = the synthetic view scatters them with ~25 small torch kernels per step (its cost, in both columns)
-    for name, mode in (("Ant", False), ("Humanoid", False), ("Ant", "device")):
-        task, st = _task(name, n, mode)
-        a = st["actions"].clone()
+    for name in ("Ant", "Humanoid", "ShadowHand", "AllegroHand", "Anymal", "Quadcopter", "BallBalance", "Ingenuity", "Crazyflie", "FrankaCabinet",
+                 "TomoDJnewhandCabinet"):
+        b = _build(name, n, False)
+        task, a = b.task, b.actions.clone()
         for _ in range(20):
             task.pre_physics_step(a); task.post_physics_step()
         torch.cuda.synchronize()
@@ -102,9 +130,9 @@ def test_replay_cost_at_the_reference_size():
         for _ in range(steps):
             task.replay_step()
         torch.cuda.synchronize()
-        out[f"{name}, view scatter {mode}"] = {"envs": n, "eager_us_per_step": eager_us, "graph_replay_us_per_step": (time.perf_counter() - t0) / steps * 1e6}
+        out[name] = {"envs": n, "eager_us_per_step": round(eager_us, 2), "graph_replay_us_per_step": round((time.perf_counter() - t0) / steps * 1e6, 2)}
     print(json.dumps(out))
-    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
         with open(os.path.join(d, "graph_step_timing.json"), "w") as f:
             json.dump(out, f, indent=1)
