@@ -636,26 +636,15 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
 #endif
 }
 
-__global__ __launch_bounds__(ANT) void anymal_scan_kernel(const AnymalPost a) {
-  __shared__ __align__(16) float s_env[TILE * AER];
-  __shared__ __align__(16) float s_k[AP * 4];
-  __shared__ __align__(16) float s_strip[(ANT / WAVE) * 256];
-  const int64_t t = blockIdx.x;
-  const int64_t left = a.n - t * TILE;
-  if (left >= TILE)
-    anymal_scan_tile<true>(a, s_env, s_k, s_strip, t, TILE);
-  else
-    anymal_scan_tile<false>(a, s_env, s_k, s_strip, t, (int)left);
-}
-
-// extras (:361-367): mean over the reset envs of each episode sum / max_episode_length_s, mean terrain level
-__global__ __launch_bounds__(1024) void anymal_extras_kernel(const AnymalPost a) {
-  __shared__ double part[1024 / WAVE][AE + 1];
+// extras (:361-367): mean over the reset envs of each episode sum / max_episode_length_s, mean terrain level.
+// One workgroup of NT threads folds the per-tile partial sums in f64.
+template <int NT>
+__device__ __forceinline__ void anymal_extras_body(const AnymalPost& a, double (*part)[AE + 1]) {
   const int64_t T = num_tiles(a.n);
   double acc[AE + 1];
 #pragma unroll
   for (int k = 0; k <= AE; ++k) acc[k] = 0.0;
-  for (int64_t i = threadIdx.x; i < T; i += 1024) {
+  for (int64_t i = threadIdx.x; i < T; i += NT) {
 #pragma unroll
     for (int k = 0; k <= AE; ++k) acc[k] += (double)a.b.reduce_workspace[i * RW + 1 + k];
   }
@@ -669,7 +658,7 @@ __global__ __launch_bounds__(1024) void anymal_extras_kernel(const AnymalPost a)
   if (threadIdx.x <= AE) {
     const int k = threadIdx.x;
     double tot = 0.0;
-    for (int i = 0; i < 1024 / WAVE; ++i) tot += part[i][k];
+    for (int i = 0; i < NT / WAVE; ++i) tot += part[i][k];
     const int64_t G = num_groups(a.n);
     const int32_t count = a.b.reset_workspace[padded_tiles(a.n) + G];
     if (k < AE) {
@@ -679,6 +668,31 @@ __global__ __launch_bounds__(1024) void anymal_extras_kernel(const AnymalPost a)
     }
     if (k == 0) *a.r.count = (int64_t)count;
   }
+}
+
+// Workgroup 0 folds the extras while the others scan (a one-workgroup, latency-bound reduction that would otherwise run
+// alone for ~12 us after the scan): workgroup b > 0 owns tile b - 1.
+__global__ __launch_bounds__(ANT) void anymal_scan_kernel(const AnymalPost a) {
+  __shared__ __align__(16) float s_env[TILE * AER];
+  __shared__ __align__(16) float s_k[AP * 4];
+  __shared__ __align__(16) float s_strip[(ANT / WAVE) * 256];
+  if (blockIdx.x == 0) {
+    static_assert(sizeof(double) * (ANT / WAVE) * (AE + 1) <= sizeof(float) * TILE * AER, "extras partials fit in s_env");
+    anymal_extras_body<ANT>(a, reinterpret_cast<double (*)[AE + 1]>(s_env));
+    return;
+  }
+  const int64_t t = (int64_t)blockIdx.x - 1;
+  const int64_t left = a.n - t * TILE;
+  if (left >= TILE)
+    anymal_scan_tile<true>(a, s_env, s_k, s_strip, t, TILE);
+  else
+    anymal_scan_tile<false>(a, s_env, s_k, s_strip, t, (int)left);
+}
+
+// stand-alone extras for reset_idx(env_ids) (no scan there)
+__global__ __launch_bounds__(1024) void anymal_extras_kernel(const AnymalPost a) {
+  __shared__ double part[1024 / WAVE][AE + 1];
+  anymal_extras_body<1024>(a, part);
 }
 
 }  // namespace oige
@@ -750,9 +764,9 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
   if (int rc = check_launch("anymal_command_norm_kernel")) return rc;
   hipLaunchKernelGGL(anymal_head_kernel, dim3((unsigned)T), dim3(WAVE), 0, st, a);
   if (int rc = check_launch("anymal_head_kernel")) return rc;
-  if (mode == 0) {
-    hipLaunchKernelGGL(anymal_scan_kernel, dim3((unsigned)T), dim3(ANT), 0, st, a);
-    if (int rc = check_launch("anymal_scan_kernel")) return rc;
+  if (mode == 0) {  // T scan workgroups + one that folds the extras
+    hipLaunchKernelGGL(anymal_scan_kernel, dim3((unsigned)T + 1), dim3(ANT), 0, st, a);
+    return check_launch("anymal_scan_kernel");
   }
   hipLaunchKernelGGL(anymal_extras_kernel, dim3(1), dim3(1024), 0, st, a);
   return check_launch("anymal_extras_kernel");
