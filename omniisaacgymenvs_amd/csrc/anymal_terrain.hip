@@ -19,6 +19,7 @@
 #include "oige_common.hpp"
 #include "oige_math.hpp"
 #include "oige_tile.hpp"
+#include "oige_scan.hpp"
 
 namespace oige {
 
@@ -112,18 +113,26 @@ __global__ __launch_bounds__(GROUP) void anymal_flags_kernel(const AnymalPost a)
   }
 }
 
-// whole-matrix norm of the reset envs' xy commands (:376): sqrt of the sum over tiles, tile order
-__global__ __launch_bounds__(1024) void anymal_command_norm_kernel(float* __restrict__ ws, int64_t tiles) {
-  __shared__ double part[1024 / WAVE];
+// Two one-workgroup reductions over what the flags kernel left, in one launch: workgroup 0 scans the per-group reset counts
+// (oige_scan.hpp), workgroup 1 takes the whole-matrix norm of the reset envs' xy commands (:376): sqrt of the sum over
+// tiles, tile order.
+__global__ __launch_bounds__(SCAN_THREADS) void anymal_scan_norm_kernel(int32_t* __restrict__ reset_ws, int64_t n_groups,
+                                                                        int64_t padded, float* __restrict__ ws, int64_t tiles) {
+  __shared__ int wave_tot[SCAN_THREADS / WAVE];
+  __shared__ double part[SCAN_THREADS / WAVE];
+  if (blockIdx.x == 0) {
+    scan_groups_body(reset_ws, n_groups, reset_ws + padded, wave_tot);
+    return;
+  }
   double acc = 0.0;
-  for (int64_t i = threadIdx.x; i < tiles; i += 1024) acc += (double)ws[i * RW];
+  for (int64_t i = threadIdx.x; i < tiles; i += SCAN_THREADS) acc += (double)ws[i * RW];
 #pragma unroll
   for (int off = WAVE / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, WAVE);
   if (lane_id() == 0) part[threadIdx.x >> 6] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
-    for (int i = 0; i < 1024 / WAVE; ++i) t += part[i];
+    for (int i = 0; i < SCAN_THREADS / WAVE; ++i) t += part[i];
     ws[tiles * RW + 0] = __builtin_sqrtf((float)t);
   }
 }
@@ -759,9 +768,9 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
   const int64_t G = num_groups(num_envs), T = num_tiles(num_envs);
   hipLaunchKernelGGL(anymal_flags_kernel, dim3((unsigned)G), dim3(GROUP), 0, st, a);
   if (int rc = check_launch("anymal_flags_kernel")) return rc;
-  if (int rc = launch_scan_groups(num_envs, b.reset_workspace, st)) return rc;
-  hipLaunchKernelGGL(anymal_command_norm_kernel, dim3(1), dim3(1024), 0, st, b.reduce_workspace, T);
-  if (int rc = check_launch("anymal_command_norm_kernel")) return rc;
+  hipLaunchKernelGGL(anymal_scan_norm_kernel, dim3(2), dim3(SCAN_THREADS), 0, st, b.reset_workspace, G, padded_tiles(num_envs),
+                     b.reduce_workspace, T);
+  if (int rc = check_launch("anymal_scan_norm_kernel")) return rc;
   hipLaunchKernelGGL(anymal_head_kernel, dim3((unsigned)T), dim3(WAVE), 0, st, a);
   if (int rc = check_launch("anymal_head_kernel")) return rc;
   if (mode == 0) {  // T scan workgroups + one that folds the extras

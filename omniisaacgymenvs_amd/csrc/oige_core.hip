@@ -10,6 +10,7 @@
 // The task kernels (locomotion.hip, cartpole.hip, ...) fuse `count` into their DONE stage and
 // `emit` into their reset stage, so a steady-state step only adds the tiny `scan` launch.
 #include "oige_common.hpp"
+#include "oige_scan.hpp"
 
 namespace oige {
 
@@ -26,45 +27,12 @@ __global__ __launch_bounds__(GROUP) void count_flags_kernel(const int64_t* __res
   if (lane_id() == 0) tile_counts[(int64_t)blockIdx.x * GROUP_TILES + (threadIdx.x >> 6)] = __popcll(mask);
 }
 
-// One workgroup of 1024 threads; thread i owns a contiguous run of groups.
-constexpr int SCAN_THREADS = 1024;
+// One workgroup of 1024 threads; thread i owns a contiguous run of groups (oige_scan.hpp).
 __global__ __launch_bounds__(SCAN_THREADS) void scan_groups_kernel(const int32_t* __restrict__ tile_counts,
                                                                    int64_t n_groups,
                                                                    int32_t* __restrict__ group_offsets) {
   __shared__ int wave_tot[SCAN_THREADS / WAVE];
-  const int tid = threadIdx.x;
-  const int64_t per = (n_groups + SCAN_THREADS - 1) / SCAN_THREADS;
-  const int64_t g0 = (int64_t)tid * per;
-  const int64_t g1 = g0 + per < n_groups ? g0 + per : n_groups;
-  const int4* c4 = reinterpret_cast<const int4*>(tile_counts);  // GROUP_TILES == 4 counts per group
-  int mine = 0;
-  for (int64_t g = g0; g < g1; ++g) {
-    const int4 c = c4[g];
-    mine += (c.x + c.y) + (c.z + c.w);
-  }
-  // inclusive scan of `mine` across the wave, then across waves
-  int incl = mine;
-#pragma unroll
-  for (int off = 1; off < WAVE; off <<= 1) {
-    const int up = __shfl_up(incl, off, WAVE);
-    if (lane_id() >= off) incl += up;
-  }
-  const int w = tid >> 6;
-  if (lane_id() == WAVE - 1) wave_tot[w] = incl;
-  __syncthreads();
-  int base = 0;
-  for (int i = 0; i < w; ++i) base += wave_tot[i];
-  int run = base + incl - mine;  // exclusive prefix at g0
-  for (int64_t g = g0; g < g1; ++g) {
-    group_offsets[g] = run;
-    const int4 c = c4[g];
-    run += (c.x + c.y) + (c.z + c.w);
-  }
-  if (tid == SCAN_THREADS - 1) {
-    int total = 0;
-    for (int i = 0; i < SCAN_THREADS / WAVE; ++i) total += wave_tot[i];
-    group_offsets[n_groups] = total;
-  }
+  scan_groups_body(tile_counts, n_groups, group_offsets, wave_tot);
 }
 
 __global__ __launch_bounds__(GROUP) void emit_ids_kernel(const int64_t* __restrict__ flags, int64_t n,
