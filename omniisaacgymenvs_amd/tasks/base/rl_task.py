@@ -128,8 +128,9 @@ class RLTask:
         if self._step_dev is not None and not self._capturing:
             self._step_dev += 1  # an eager step between replays: keep the captured graph's counter in step
 
-    def capture_step(self, actions: torch.Tensor) -> None:
-        """Capture ``pre_physics_step(actions); post_physics_step()`` into one HIP graph (torch.cuda.CUDAGraph on ROCm).
+    def capture_step(self, actions: torch.Tensor, split: bool = False) -> None:
+        """Capture ``pre_physics_step(actions); post_physics_step()`` into one HIP graph (torch.cuda.CUDAGraph on ROCm), or
+        with ``split=True`` into two (``replay_pre()`` / ``replay_post()``), for a physics step that runs between them.
 
         At the reference's own sizes (4096 envs) the step is bound by launches and Python marshalling, not by the GPU; a
         replay is one graph launch.  ``actions`` is the static input buffer: refill it in place (``actions.copy_(...)``)
@@ -160,22 +161,38 @@ class RLTask:
                 self.pre_physics_step(actions)
                 self.post_physics_step()
             torch.cuda.current_stream(dev).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
+            graph, graph_post = torch.cuda.CUDAGraph(), None
             count0 = getattr(self, "_step_count", 0)
             with torch.cuda.graph(graph, stream=side):
                 self._step_dev += 1
                 self.pre_physics_step(actions)
-                self.post_physics_step()
+                if not split:
+                    self.post_physics_step()
+            if split:
+                graph_post = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph_post, stream=side):
+                    self.post_physics_step()
             self._step_count = count0  # the captured step has not run yet
         finally:
             self._capturing = False
-        self._graph, self._graph_actions = graph, actions
+        self._graph, self._graph_post, self._graph_actions = graph, graph_post, actions
 
     def replay_step(self):
         """One captured step; returns what ``post_physics_step`` returns.  ``task._graph_actions`` holds the actions."""
+        self.replay_pre()
+        if self._graph_post is not None:
+            return self.replay_post()
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def replay_pre(self) -> None:
+        """The captured ``pre_physics_step`` (with ``split=False``: the whole step)."""
         self._graph.replay()
         self._step_count = getattr(self, "_step_count", 0) + 1
         self._counts_key = None
+
+    def replay_post(self):
+        """The captured ``post_physics_step`` of a ``split=True`` capture."""
+        self._graph_post.replay()
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     # ------------------------------------------------------------------ RL interface

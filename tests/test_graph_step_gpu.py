@@ -53,6 +53,31 @@ def _tensors(task):
     return out
 
 
+@pytest.mark.parametrize("name,n", [("Ant", 1000), ("ShadowHand", 500), ("FrankaCabinet", 500)])
+def test_split_capture_equals_eager_steps(name, n):
+    """Two graphs (pre / post), for a physics step in between: same results as the eager calls."""
+    eager, graph = _build(name, n, True), _build(name, n, "device")
+    g = torch.Generator().manual_seed(4)
+    acts = [(torch.rand(n, eager.task.num_actions, generator=g) * 2 - 1).to("cuda:0") for _ in range(4)]
+    static = acts[0].clone()
+    te, tg = eager.task, graph.task
+    tg.capture_step(static, split=True)
+    te.pre_physics_step(acts[0])
+    te.post_physics_step()
+    for a in acts[1:]:
+        static.copy_(a)
+        tg.replay_pre()
+        te.pre_physics_step(a)
+        torch.cuda.synchronize()
+        assert_equal(tg.reset_buf, te.reset_buf, "reset_buf after pre")
+        tg.replay_post()
+        te.post_physics_step()
+        torch.cuda.synchronize()
+        A_, B_ = _tensors(te), _tensors(tg)
+        for key in A_:
+            assert_equal(B_[key], A_[key], key)
+
+
 @pytest.mark.parametrize("name,n", CASES)
 def test_graph_replay_equals_eager_steps(name, n):
     eager, graph = _build(name, n, True), _build(name, n, "device")   # host-applied vs device-applied reset rows
