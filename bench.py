@@ -702,8 +702,9 @@ def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:
     return out
 
 
-def cpu_baseline(task_name: str, n: int, budget_s: float = 12.0):
-    """The oracle (CPU torch restatement of the reference) timed on the host cores: bounded sample."""
+def cpu_baseline(task_name: str, n: int, budget_s: float = 10.0):
+    """The oracle (CPU torch restatement of the reference) timed on the host cores: a bounded sample of about ``budget_s``
+    seconds of CPU work (at least 20 steps)."""
     step = ADAPTERS[task_name].cpu_baseline(task_name, n, budget_s)
     step()  # warm-up
     t0 = time.perf_counter()
@@ -711,7 +712,8 @@ def cpu_baseline(task_name: str, n: int, budget_s: float = 12.0):
     while True:
         step()
         k += 1
-        if time.perf_counter() - t0 > budget_s or k >= 20:
+        el = time.perf_counter() - t0
+        if (el > budget_s and k >= 20) or el > 3 * budget_s:
             break
     dt = (time.perf_counter() - t0) / k
     return {
