@@ -1,0 +1,79 @@
+"""-m gpu: the HIP path (task mirrors -> C ABI) against the golden vectors of the SURVEY.md 8f rank-3 / rank-4 tasks, which
+oracle/gen_golden_tasks.py produced by running the reference's own method source (tests/golden/task_*.npz).  Bar: progress
+bit-exact; fp32 within 1e-5 rel / 1e-6 abs; reset / terminate flags bit-exact and rewards in tolerance except for at most two
+envs per file (the fixtures hold rows one ulp either side of a decision threshold, which fp32 reassociation may flip)."""
+import os
+
+import pytest
+import torch
+
+import golden_tasks as gt
+from helpers import assert_close, assert_equal, make_task
+from omniisaacgymenvs_amd.sim import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(name, task, st, b, spec):
+    dev = task.device
+    if "env_pos" in st:
+        task._env_pos.copy_(st["env_pos"].to(dev))
+    common = dict(progress=b["progress_buf"], reset=b["reset_buf"])
+    if name == "Quadcopter":
+        workloads.load_quadcopter_state(task, dict(st, targets=b["dof_position_targets"], thrusts=b["thrusts"], **common))
+        task.target_positions.copy_(b["target_positions"].to(dev))
+    elif name == "BallBalance":
+        workloads.load_ball_balance_state(task, dict(st, targets=b["dof_position_targets"], **common))
+    elif name == "Ingenuity":
+        workloads.load_ingenuity_state(task, dict(st, targets=b["target_positions"], dof_pos=b["dof_pos"], dof_vel=b["dof_vel"], **common))
+    elif name == "Crazyflie":
+        from oracle.crazyflie_oracle import EPISODE_KEYS
+
+        sums = torch.stack([b["episode_sums"][k] for k in EPISODE_KEYS])
+        workloads.load_crazyflie_state(task, dict(st, targets=b["target_positions"], prev_actions=b["actions"], cmds_damp=b["thrust_cmds_damp"],
+                                                  rot_damp=b["thrust_rot_damp"], episode_sums=sums, **common))
+    elif name in ("FrankaCabinet", "TomoDJCabinet", "TomoSPCCabinet"):
+        workloads.load_franka_cabinet_state(task, dict(st, prev_actions=b["actions"], targets=b["franka_dof_targets"], **common))
+        task._rows_host["franka_local_grasp_pos"] = list(spec.franka_local_grasp_pos)   # the fixture's stand-in for the USD-derived pose
+        task._rows_host["franka_local_grasp_rot"] = list(spec.franka_local_grasp_rot)
+    else:
+        workloads.load_newhand_cabinet_state(task, dict(st, prev_actions=b["actions"], targets=b["dof_targets"], terminate=b["terminate_buf"],
+                                                        **common))
+
+
+def _mostly(got, want, what, max_bad=2, flags=False):
+    got, want = got.detach().cpu(), want.detach().cpu()
+    assert got.shape == want.shape and got.dtype == want.dtype, what
+    if flags:
+        bad = got != want
+    else:
+        bad = ((got - want).abs() > 1e-5 * want.abs() + 1e-6) | (got.isnan() != want.isnan())
+    rows = bad.reshape(bad.shape[0], -1).any(-1)
+    assert int(rows.sum()) <= max_bad, f"{what}: {int(rows.sum())} rows differ (first: {rows.nonzero()[:5].flatten().tolist()})"
+
+
+@pytest.mark.parametrize("name", list(gt.FAMILIES))
+def test_hip_reproduces_task_golden(name):
+    fam = gt.FAMILIES[name]
+    spec = fam.spec()
+    for path in gt.files(name):
+        tag = os.path.basename(path)
+        g = gt.load(path)
+        st, b, want = gt.unflatten(g, "st"), gt.unflatten(g, "b"), gt.unflatten(g, "out")
+        n = want["obs_buf"].shape[0]
+        env, task = make_task(name, n)
+        _load(name, task, st, b, spec)
+        obs, rew, reset, _ = task.post_physics_step()
+        torch.cuda.synchronize()
+        assert_equal(task.progress_buf, want["progress_buf"], f"{tag} progress_buf")
+        assert_close(obs, want["obs_buf"], f"{tag} obs_buf")
+        _mostly(reset, want["reset_buf"], f"{tag} reset_buf", flags=True)
+        _mostly(rew, want["rew_buf"], f"{tag} rew_buf")
+        for k in fam.extra_out:
+            if k == "episode_sums":
+                for kk, w in want[k].items():
+                    _mostly(task.episode_sums[kk], w, f"{tag} episode_sums[{kk}]")
+            elif k == "terminate_buf":
+                _mostly(task.terminate_buf, want[k], f"{tag} terminate_buf", flags=True)
+            else:
+                assert_close(getattr(task, k), want[k], f"{tag} {k}")
