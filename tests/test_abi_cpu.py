@@ -38,6 +38,8 @@ def test_struct_layouts_match_the_c_header(tmp_path):
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "oige_hip.h"\nint main(void){\n'
     for n in sorted(structs):
         src += f'  printf("{n} %zu\\n", sizeof({cname(n)}));\n'
+        for fname, *_ in structs[n]._fields_:   # every field sits where the C compiler puts it (same names on both sides)
+            src += f'  printf("{n}.{fname} %zu\\n", offsetof({cname(n)}, {fname}));\n'
     src += '  printf("lower %zu\\n", offsetof(oige_locomotion_params, dof_limits_lower));\n'
     src += '  printf("count %zu\\n", offsetof(oige_locomotion_reset_io, count));\n  return 0;\n}\n'
     c = tmp_path / "sz.c"
@@ -47,6 +49,8 @@ def test_struct_layouts_match_the_c_header(tmp_path):
     out = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
     for n, cls in structs.items():
         assert int(out[n]) == ctypes.sizeof(cls), f"{n}: C {out[n]} vs ctypes {ctypes.sizeof(cls)}"
+        for fname, *_ in cls._fields_:
+            assert int(out[f"{n}.{fname}"]) == getattr(cls, fname).offset, f"{n}.{fname}: C offset {out[f'{n}.{fname}']} vs ctypes {getattr(cls, fname).offset}"
     assert int(out["lower"]) == _lib.LocomotionParams.dof_limits_lower.offset
     assert int(out["count"]) == _lib.LocomotionResetIO.count.offset
 
