@@ -538,6 +538,7 @@ typedef struct oige_noise_args {
   float reserved0;
   oige_noise_term on_reset;
   oige_noise_term on_interval;
+  const uint64_t* step_ptr;      /* NULL, or a device scalar read INSTEAD of `step` (HIP-graph replay of the wrapper's step) */
 } oige_noise_args;
 
 /* First half of the exact-replay flow: decides reset ids (:284) and randomize ids (:299-303) WITHOUT

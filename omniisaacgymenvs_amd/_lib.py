@@ -331,11 +331,11 @@ class NoiseTerm(C.Structure):
 
 
 class NoiseArgs(C.Structure):
-    _fields_ = [(n, _fp) for n in (
+    _fields_ = ([(n, _fp) for n in (
         "buffer", "reset_buf", "counter", "correlated_noise", "clamped_out", "reset_samples", "interval_samples",
         "reset_workspace", "interval_workspace")] + [
         ("seed", C.c_uint64), ("step", C.c_uint64), ("stream_id", C.c_int32), ("width", C.c_int32), ("clip", _f),
-        ("reserved0", _f), ("on_reset", NoiseTerm), ("on_interval", NoiseTerm)]
+        ("reserved0", _f), ("on_reset", NoiseTerm), ("on_interval", NoiseTerm)]) + [("step_ptr", _fp)]
 
 
 # name -> (restype, argtypes); every symbol include/oige_hip.h declares

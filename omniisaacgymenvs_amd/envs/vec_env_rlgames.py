@@ -135,6 +135,65 @@ class VecEnvRLGames(VecEnvBase):
         obs_dict = {"obs": self._obs, "states": self._states}
         return obs_dict, self._rew, self._resets, self._extras
 
+    # ------------------------------------------------------------------ HIP-graph step (launch-bound sizes)
+    def capture_step(self, actions: torch.Tensor) -> None:
+        """Capture the whole ``step(actions)`` -- action noise / clamp, ``pre_physics_step``, the (delegated) world step,
+        ``post_physics_step``, observation noise / clamp -- into one HIP graph.  ``actions`` is the static input buffer (refill
+        it in place before each ``replay_step()``).  Needs the fused wrapper flow (``fused_io``), a sync-free capturable task
+        (``RLTask.capture_step``) and the sync-free randomizer.  The Philox step counters of the task and of the two noise
+        streams are read from device scalars the graph advances (``step_ptr``), so replayed steps draw what eager steps would.
+        One eager ``step`` runs first as warm-up; the second one is captured, not executed."""
+        t = self._task
+        if t.graph_capturable is not True:
+            raise NotImplementedError(f"{type(t).__name__}: {t.graph_capturable}")
+        if not (self.fused_io and getattr(t, "sync_free", False) and getattr(t, "fused", False)):
+            raise RuntimeError("capture_step needs env.fused_io and the task's sync-free fused path")
+        dr = getattr(t, "_dr_randomizer", None)
+        if dr is not None and (t.randomize_actions or t.randomize_observations) and not dr.sync_free:
+            raise RuntimeError("capture_step needs the sync-free randomizer (in-kernel Philox samples)")
+        dev = t.obs_buf.device
+        t._step_dev = torch.full((1,), getattr(t, "_step_count", 0), dtype=torch.int64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        t._capturing = True
+        if dr is not None:
+            dr.capturing = True
+        try:
+            with torch.cuda.stream(side):
+                t._step_dev += 1
+                self.step(actions)  # warm-up
+            torch.cuda.current_stream(dev).wait_stream(side)
+            host = (getattr(t, "_step_count", 0), getattr(dr, "_observations_step", 0), getattr(dr, "_actions_step", 0))
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                t._step_dev += 1
+                out = self.step(actions)
+            t._step_count = host[0]  # the captured step has not run yet
+            if dr is not None:
+                if hasattr(dr, "_observations_step"):
+                    dr._observations_step = host[1]
+                if hasattr(dr, "_actions_step"):
+                    dr._actions_step = host[2]
+        finally:
+            t._capturing = False
+            if dr is not None:
+                dr.capturing = False
+        self._graph, self._graph_out, self._graph_actions = graph, out, actions
+
+    def replay_step(self):
+        """One captured ``step``: returns the same ``(obs_dict, rew, resets, extras)`` objects, refreshed in place."""
+        t = self._task
+        self._graph.replay()
+        t._step_count = getattr(t, "_step_count", 0) + 1
+        t._counts_key = None
+        dr = getattr(t, "_dr_randomizer", None)
+        if dr is not None:
+            if hasattr(dr, "_observations_step") and t.randomize_observations:
+                dr._observations_step += 1
+            if hasattr(dr, "_actions_step") and t.randomize_actions:
+                dr._actions_step += 1
+        return self._graph_out
+
     def reset(self, seed=None, options=None):
         """Flag all envs, then one zero-action step to recompute observations and states."""
         now = datetime.now().strftime("%Y-%m-%d %H:%M:%S")

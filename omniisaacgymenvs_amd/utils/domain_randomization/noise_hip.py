@@ -66,7 +66,7 @@ class NoiseState:
 
 def build_args(buffer: torch.Tensor, reset_buf: Optional[torch.Tensor], counter: torch.Tensor, correlated: torch.Tensor,
                params: Dict[str, Any], seed: int, stream_id: int, step: int, clamped_out: Optional[torch.Tensor] = None,
-               clip: float = math.inf) -> _lib.NoiseArgs:
+               clip: float = math.inf, step_ptr: Optional[int] = None) -> _lib.NoiseArgs:
     """The argument block of the in-kernel-Philox flow; also what the in-hand kernels take to apply the noise themselves
     (``oige_hand_post_physics_dr`` / ``oige_hand_pre_physics_dr``: they hold the reset flags in registers, ``reset_buf`` is
     not read and may be None)."""
@@ -85,13 +85,14 @@ def build_args(buffer: torch.Tensor, reset_buf: Optional[torch.Tensor], counter:
         a.clamped_out = clamped_out.data_ptr()
         a.clip = float(min(clip, 3.0e38))
     a.seed, a.step, a.stream_id, a.width = int(seed) & 0xFFFFFFFFFFFFFFFF, int(step), int(stream_id), int(w)
+    a.step_ptr = step_ptr  # graph capture: the Philox step counter lives on the device
     a.on_reset, a.on_interval = _term(params, "on_reset"), _term(params, "on_interval")
     return a
 
 
 def apply(buffer: torch.Tensor, reset_buf: torch.Tensor, counter: torch.Tensor, correlated: torch.Tensor,
           params: Dict[str, Any], state: NoiseState, seed: int, stream_id: int, step: int, sync_free: bool = True,
-          clamped_out: Optional[torch.Tensor] = None, clip: float = math.inf) -> torch.Tensor:
+          clamped_out: Optional[torch.Tensor] = None, clip: float = math.inf, step_ptr: Optional[int] = None) -> torch.Tensor:
     n, w = buffer.shape
     rq = _lib.require_device_tensor
     rq(buffer, torch.float32, (n, w), "noise buffer")
@@ -108,6 +109,7 @@ def apply(buffer: torch.Tensor, reset_buf: torch.Tensor, counter: torch.Tensor, 
         a.clamped_out = clamped_out.data_ptr()
         a.clip = float(min(clip, 3.0e38))
     a.seed, a.step, a.stream_id, a.width = int(seed) & 0xFFFFFFFFFFFFFFFF, int(step), int(stream_id), int(w)
+    a.step_ptr = step_ptr  # graph capture: the Philox step counter lives on the device
     a.on_reset, a.on_interval = _term(params, "on_reset"), _term(params, "on_interval")
     lib, stream = _lib.load(), _lib.current_stream(buffer.device)
     keep = []

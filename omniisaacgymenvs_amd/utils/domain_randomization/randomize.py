@@ -91,17 +91,31 @@ class Randomizer:
     # ``sync_free`` (default): samples from in-kernel Philox, no host sync.  ``sync_free = False``: the reference's
     # flow with torch's RNG (ids compacted on the device, counts read back, torch.normal / torch.rand draws).
     sync_free = True
+    capturing = False   # set by VecEnvRLGames.capture_step: step counters are read from (and advanced on) the device
+
+    def _advance(self, what: str, device) -> Optional[int]:
+        """Advance the host step counter of ``what`` ("observations" / "actions"); while a step is being captured (or once one
+        has been) a device twin is advanced on the stream too.  Returns the twin's address while capturing, else None."""
+        name, dev_name = f"_{what}_step", f"_{what}_step_dev"
+        setattr(self, name, getattr(self, name) + 1)
+        twin = getattr(self, dev_name, None)
+        if self.capturing and twin is None:
+            twin = torch.full((1,), getattr(self, name) - 1, dtype=torch.int64, device=device)
+            setattr(self, dev_name, twin)
+        if twin is not None:
+            twin += 1
+        return twin.data_ptr() if (self.capturing and twin is not None) else None
 
     def apply_observations_randomization(self, observations, reset_buf, clamped_out=None, clip=float("inf")):
         from . import noise_hip
 
         if not hasattr(self, "_observations_noise_state"):
             self._observations_noise_state = noise_hip.NoiseState(observations.shape[0], observations.device)
-        self._observations_step += 1
+        sp = self._advance("observations", observations.device)
         return noise_hip.apply(
             observations, reset_buf, self._observations_counter_buffer, self._observations_correlated_noise,
             self._observations_dr_params, self._observations_noise_state, seed=int(self._config.get("seed", 0)),
-            stream_id=0, step=self._observations_step, sync_free=self.sync_free, clamped_out=clamped_out, clip=clip,
+            stream_id=0, step=self._observations_step, sync_free=self.sync_free, clamped_out=clamped_out, clip=clip, step_ptr=sp,
         )
 
     # The in-hand kernels apply the noise in their own epilogue / prologue (SURVEY.md 8f rank 1): these hand them the
@@ -109,28 +123,28 @@ class Randomizer:
     def fused_observations_args(self, observations, clamped_out=None, clip=float("inf")):
         from . import noise_hip
 
-        self._observations_step += 1
+        sp = self._advance("observations", observations.device)
         return noise_hip.build_args(
             observations, None, self._observations_counter_buffer, self._observations_correlated_noise,
             self._observations_dr_params, seed=int(self._config.get("seed", 0)), stream_id=0, step=self._observations_step,
-            clamped_out=clamped_out, clip=clip)
+            clamped_out=clamped_out, clip=clip, step_ptr=sp)
 
     def fused_actions_args(self, actions):
         from . import noise_hip
 
-        self._actions_step += 1
+        sp = self._advance("actions", actions.device)
         return noise_hip.build_args(
             actions, None, self._actions_counter_buffer, self._actions_correlated_noise, self._actions_dr_params,
-            seed=int(self._config.get("seed", 0)), stream_id=1, step=self._actions_step)
+            seed=int(self._config.get("seed", 0)), stream_id=1, step=self._actions_step, step_ptr=sp)
 
     def apply_actions_randomization(self, actions, reset_buf, clamped_out=None, clip=float("inf")):
         from . import noise_hip
 
         if not hasattr(self, "_actions_noise_state"):
             self._actions_noise_state = noise_hip.NoiseState(actions.shape[0], actions.device)
-        self._actions_step += 1
+        sp = self._advance("actions", actions.device)
         return noise_hip.apply(
             actions, reset_buf, self._actions_counter_buffer, self._actions_correlated_noise,
             self._actions_dr_params, self._actions_noise_state, seed=int(self._config.get("seed", 0)),
-            stream_id=1, step=self._actions_step, sync_free=self.sync_free, clamped_out=clamped_out, clip=clip,
+            stream_id=1, step=self._actions_step, sync_free=self.sync_free, clamped_out=clamped_out, clip=clip, step_ptr=sp,
         )

@@ -156,6 +156,27 @@ def test_replay_cost_at_the_reference_size():
             task.replay_step()
         torch.cuda.synchronize()
         out[name] = {"envs": n, "eager_us_per_step": round(eager_us, 2), "graph_replay_us_per_step": round((time.perf_counter() - t0) / steps * 1e6, 2)}
+    for name in ("ShadowHand", "Ant"):   # the wrapper's whole step (ShadowHand: DR noise on observations and actions + clamps)
+        b = _build(name, n, False)
+        env, a = b.env, b.actions.clone()
+        for _ in range(20):
+            env.step(a)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            env.step(a)
+        torch.cuda.synchronize()
+        eager_us = (time.perf_counter() - t0) / steps * 1e6
+        env.capture_step(a)
+        for _ in range(20):
+            env.replay_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            env.replay_step()
+        torch.cuda.synchronize()
+        out[f"{name} VecEnvRLGames.step"] = {"envs": n, "eager_us_per_step": round(eager_us, 2),
+                                             "graph_replay_us_per_step": round((time.perf_counter() - t0) / steps * 1e6, 2)}
     print(json.dumps(out))
     d = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(d):
@@ -163,3 +184,47 @@ def test_replay_cost_at_the_reference_size():
             json.dump(out, f, indent=1)
     for rec in out.values():   # a measurement, not a gate: only a gross regression fails (the boxes are shared, timings jitter)
         assert rec["graph_replay_us_per_step"] < 2.0 * rec["eager_us_per_step"]
+
+
+@pytest.mark.parametrize("cfg,n", [("ShadowHand", 700), ("AllegroHand", 300), ("Ant", 1000), ("FrankaCabinet", 500)])
+def test_wrapper_capture_equals_eager_env_steps(cfg, n):
+    """VecEnvRLGames.capture_step: action noise / clamp + task step + observation noise / clamp in one graph, bit-identical to
+    eager env.step() calls (ShadowHand carries the reference's DR noise on both observations and actions)."""
+    def build(mode):
+        b = _build(cfg, n, mode)   # the bench adapter: a task with a loaded synthetic state (resets every step)
+        return b.env, b.task
+
+    (ee, te), (eg, tg) = build(True), build("device")
+    g = torch.Generator().manual_seed(5)
+    acts = [(torch.rand(n, te.num_actions, generator=g) * 3 - 1.5).to("cuda:0") for _ in range(6)]
+    static = acts[0].clone()
+    eg.capture_step(static)
+    ee.step(acts[0].clone())
+    resets_seen = 0
+    for a in acts[1:]:
+        static.copy_(a)
+        og, rg, dg, _ = eg.replay_step()
+        oe, re_, de, _ = ee.step(a.clone())
+        torch.cuda.synchronize()
+        assert_equal(og["obs"], oe["obs"], "obs")
+        assert_equal(rg, re_, "rew")
+        assert_equal(dg, de, "resets")
+        if tg.num_states > 0:
+            assert_equal(og["states"], oe["states"], "states")
+        A_, B_ = _tensors(te), _tensors(tg)
+        for key in A_:
+            assert_equal(B_[key], A_[key], key)
+        resets_seen += int(de.sum())
+    if cfg in ("ShadowHand", "Ant"):   # their synthetic states keep producing resets after the first step
+        assert resets_seen > 0
+    dr_e, dr_g = getattr(te, "_dr_randomizer", None), getattr(tg, "_dr_randomizer", None)
+    if dr_e is not None and te.randomize_observations:
+        assert dr_g._observations_step == dr_e._observations_step and dr_g._actions_step == dr_e._actions_step
+        assert_equal(dr_g._observations_correlated_noise, dr_e._observations_correlated_noise, "correlated observation noise")
+    # an eager env.step between replays keeps every device counter in step
+    ee.step(acts[1].clone()); eg.step(acts[1].clone())
+    static.copy_(acts[2])
+    og, _, _, _ = eg.replay_step()
+    oe, _, _, _ = ee.step(acts[2].clone())
+    torch.cuda.synchronize()
+    assert_equal(og["obs"], oe["obs"], "obs after a mixed eager/replay sequence")
