@@ -25,6 +25,8 @@ def global_config(**overrides: Any) -> Dict[str, Any]:
         "recording_interval": 2000,
         "recording_length": 100,
         "multi_gpu": False,
+        "warp": False,
+        "task_name": "Cartpole",
     }
     cfg.update(overrides)
     return cfg
@@ -111,6 +113,9 @@ _OPENAI_FF_ENV.update({
 })
 TASK_DEFAULTS["ShadowHandOpenAI_FF"] = {"name": "ShadowHand", "env": _OPENAI_FF_ENV, "sim": dict(_SIM),
                                        "domain_randomization": copy.deepcopy(_SHADOW_HAND_DR)}
+
+# cfg/task/ShadowHandOpenAI_LSTM.yaml:3-8: the FF task YAML unchanged (the LSTM lives in the train YAML, out of scope)
+TASK_DEFAULTS["ShadowHandOpenAI_LSTM"] = copy.deepcopy(TASK_DEFAULTS["ShadowHandOpenAI_FF"])
 
 # cfg/task/AllegroHand.yaml:7-42 (no asymmetric observations, no force perturbation keys, no domain_randomization section)
 _ALLEGRO_HAND_ENV = {k: v for k, v in _SHADOW_HAND_ENV.items()
@@ -261,7 +266,9 @@ class SimConfig:
 
     def __init__(self, config: Optional[Dict[str, Any]] = None, task_config_: Optional[Dict[str, Any]] = None):
         self._config = config if config is not None else global_config()
-        self._task_config = task_config_ if task_config_ is not None else {}
+        if task_config_ is None:  # the reference's form: SimConfig(config) with the task YAML under config["task"]
+            task_config_ = self._config.get("task", {})
+        self._task_config = task_config_
         self._config.setdefault("task", self._task_config)
 
     @property
@@ -271,6 +278,13 @@ class SimConfig:
     @property
     def task_config(self) -> Dict[str, Any]:
         return self._task_config
+
+    def get_physics_params(self) -> Dict[str, Any]:
+        """The ``sim`` section of the task YAML plus ``rendering_dt`` (sim_config.py: get_physics_params, as
+        task_util.py:124-131 reads it); nothing here drives a solver, the synthetic world ignores it."""
+        sim = dict(self._task_config.get("sim", {}))
+        sim.setdefault("rendering_dt", sim.get("dt", 1.0 / 60.0))
+        return sim
 
     # no-ops kept so reference-style task code can call them
     def apply_articulation_settings(self, *a, **k) -> None:

@@ -12,33 +12,13 @@ RTOL, ATOL = 1e-5, 1e-6
 
 
 def make_task(name: str, n: int, device: str = "cuda:0", seed: int = 42, **env_overrides):
-    from omniisaacgymenvs_amd.tasks.ant import AntLocomotionTask
-    from omniisaacgymenvs_amd.tasks.cartpole import CartpoleTask
-    from omniisaacgymenvs_amd.tasks.humanoid import HumanoidLocomotionTask
+    """Through the reference's own front door: initialize_task(config, env) (utils/task_util.py:109-132)."""
+    from omniisaacgymenvs_amd.utils.task_util import initialize_task
 
-    from omniisaacgymenvs_amd.tasks.allegro_hand import AllegroHandTask
-    from omniisaacgymenvs_amd.tasks.anymal import AnymalTask
-    from omniisaacgymenvs_amd.tasks.ball_balance import BallBalanceTask
-    from omniisaacgymenvs_amd.tasks.crazyflie import CrazyflieTask
-    from omniisaacgymenvs_amd.tasks.franka_cabinet import FrankaCabinetTask
-    from omniisaacgymenvs_amd.tasks.tomodj_cabinet import TomoDJCabinetTask, TomoSPCCabinetTask
-    from omniisaacgymenvs_amd.tasks.newhand_cabinet import (TomoDJnewhandCabinetTask, TomoDJnewhandTendonCabinetTask,
-                                                            TomoSPCnewhandCabinetTask)
-    from omniisaacgymenvs_amd.tasks.ingenuity import IngenuityTask
-    from omniisaacgymenvs_amd.tasks.quadcopter import QuadcopterTask
-    from omniisaacgymenvs_amd.tasks.anymal_terrain import AnymalTerrainTask
-    from omniisaacgymenvs_amd.tasks.shadow_hand import ShadowHandTask
-
-    cls = {"Ant": AntLocomotionTask, "Humanoid": HumanoidLocomotionTask, "Cartpole": CartpoleTask,
-           "ShadowHand": ShadowHandTask, "ShadowHandOpenAI_FF": ShadowHandTask, "AnymalTerrain": AnymalTerrainTask,
-           "Anymal": AnymalTask, "AllegroHand": AllegroHandTask, "Quadcopter": QuadcopterTask, "BallBalance": BallBalanceTask, "Ingenuity": IngenuityTask, "Crazyflie": CrazyflieTask, "FrankaCabinet": FrankaCabinetTask, "TomoDJCabinet": TomoDJCabinetTask,
-            "TomoSPCCabinet": TomoSPCCabinetTask, "TomoDJnewhandCabinet": TomoDJnewhandCabinetTask,
-            "TomoDJnewhandTendonCabinet": TomoDJnewhandTendonCabinetTask, "TomoSPCnewhandCabinet": TomoSPCnewhandCabinetTask}[name]
-    cfg = global_config(sim_device=device, rl_device=device, seed=seed)
-    sim_config = SimConfig(cfg, task_config(name, num_envs=n, **env_overrides))
+    cfg = global_config(sim_device=device, rl_device=device, seed=seed, task_name=name,
+                        task=task_config(name, num_envs=n, **env_overrides))
     env = VecEnvRLGames(headless=True)
-    task = cls(name=name, sim_config=sim_config, env=env)
-    env.set_task(task, backend="torch")
+    task = initialize_task(cfg, env)
     return env, task
 
 
