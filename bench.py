@@ -730,6 +730,11 @@ def main() -> None:
     ap.add_argument("--envs", type=int, default=0, help="envs per GPU (default: the BASELINE.json config's per-GPU size)")
     ap.add_argument("--task", default="Ant", choices=sorted(ADAPTERS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the whole step as one HIP graph (RLTask.capture_step): the launch-bound regime of the "
+                         "reference's own sizes, e.g. --envs 4096 (not for ShadowHand's DR adapter or AnymalTerrain)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --envs per GPU (default); strong: the one-GPU env count split over the ranks")
     ap.add_argument("--cpu-envs", type=int, default=0)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="PMC-derived HBM bytes per launch of the dominant kernel (profiles/run_profiles.sh) -> roofline.traffic")
@@ -760,6 +765,10 @@ def main() -> None:
     from omniisaacgymenvs_amd.utils import distributed as od
 
     n = args.envs or DEFAULT_ENVS[args.task]
+    if args.scaling == "strong":
+        if n % (64 * world):
+            raise SystemExit(f"--scaling strong: {n} envs do not split into {world} ranks of whole 64-env tiles")
+        n //= world
     with contextlib.redirect_stdout(sys.stderr):  # the task constructors print like the reference's; stdout carries ONE JSON line
         bench = ADAPTERS[args.task](args.task, n, dev, od.rank_seed(1234, rank))
 
@@ -768,6 +777,13 @@ def main() -> None:
     ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     after = getattr(bench, "after_post", lambda: None)
+    if args.graph:
+        if hasattr(bench, "after_post"):  # HandBench: noise arguments per call, wrapper-side leg
+            raise SystemExit(f"--graph: the {args.task} adapter does more than the two task calls per step; "
+                             "see tests/test_graph_step_gpu.py for its captured step")
+        with contextlib.redirect_stdout(sys.stderr):
+            bench.task.capture_step(bench.actions)  # raises for AnymalTerrain (host-side branch in its step)
+        bench.pre, bench.post = bench.task.replay_step, (lambda: None)
 
     def timed_step(es, e0, e1):
         es.record()
@@ -790,8 +806,14 @@ def main() -> None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for es, (e0, e1) in zip(ev_start, ev_pairs):
-        timed_step(es, e0, e1)
+    if args.graph:  # one graph launch per step, nothing else on the stream; events only around the whole loop
+        ev_start[0].record()
+        for _ in range(args.steps):
+            bench.pre()
+        ev_pairs[-1][1].record()
+    else:
+        for es, (e0, e1) in zip(ev_start, ev_pairs):
+            timed_step(es, e0, e1)
     # episode statistics [sum reward, n done, sum episode length of done envs, successes, n envs]: the path's only
     # cross-rank exchange, one 40-byte all-reduce over RCCL (utils/distributed.py)
     t = bench.task
@@ -806,8 +828,11 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    post_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
-    pre_ms = sum(es.elapsed_time(e0) for es, (e0, _) in zip(ev_start, ev_pairs)) / len(ev_pairs)
+    if args.graph:  # the kernels are nodes of one graph: the whole replayed step stands in for the post kernel (a lower bound)
+        post_ms, pre_ms = ev_start[0].elapsed_time(ev_pairs[-1][1]) / len(ev_pairs), None
+    else:
+        post_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
+        pre_ms = sum(es.elapsed_time(e0) for es, (e0, _) in zip(ev_start, ev_pairs)) / len(ev_pairs)
     gpu_span_ms = ev_start[0].elapsed_time(ev_pairs[-1][1]) / len(ev_pairs)  # first pre launch -> last post end, per step
     copy_gbs = measured_copy_gbs(dev, bench.post_bytes * n) if rank == 0 else None
     achieved = bench.post_bytes * n / (post_ms * 1e-3) / 1e9
@@ -822,6 +847,8 @@ def main() -> None:
         cfg = {"workload": bench.workload, "envs_per_gpu": n, "resets_per_step": bench.resets(),
                "step": "pre_physics_step + post_physics_step via RLTask API (physics delegated)"}
         cfg.update(bench.extra_cfg)
+        if args.graph:
+            cfg["step"] += ", replayed as one HIP graph (RLTask.capture_step)"
         cfg["episode_stats"] = {k: round(v, 4) for k, v in job_stats.items()}
         out = {
             "metric": "fused obs+reward+reset env-steps/s",
@@ -832,13 +859,13 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": cfg,
             "roofline": {
-                "bound": "hbm", "kernel": bench.kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                "bound": "hbm", "kernel": bench.kernel + (" (+ pre_physics: whole replayed graph timed)" if args.graph else ""), "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_env": bench.post_bytes, "avg_kernel_ms": post_ms,
                 "pre_physics_ms": pre_ms, "gpu_ms_per_step": gpu_span_ms,

@@ -111,8 +111,9 @@ _OPENAI_FF_ENV.update({
     "fallPenalty": -50.0, "observationType": "openai", "asymmetric_observations": True, "successTolerance": 0.4,
     "maxConsecutiveSuccesses": 50, "averFactor": 0.1,
 })
-TASK_DEFAULTS["ShadowHandOpenAI_FF"] = {"name": "ShadowHand", "env": _OPENAI_FF_ENV, "sim": dict(_SIM),
+TASK_DEFAULTS["ShadowHandOpenAI_FF"] = {"name": "ShadowHand", "env": _OPENAI_FF_ENV, "sim": dict(_SIM, dt=0.016667),  # :55
                                        "domain_randomization": copy.deepcopy(_SHADOW_HAND_DR)}
+TASK_DEFAULTS["ShadowHandOpenAI_FF"]["domain_randomization"]["randomize"] = True  # ShadowHandOpenAI_FF.yaml:138 (ShadowHand.yaml: False)
 
 # cfg/task/ShadowHandOpenAI_LSTM.yaml:3-8: the FF task YAML unchanged (the LSTM lives in the train YAML, out of scope)
 TASK_DEFAULTS["ShadowHandOpenAI_LSTM"] = copy.deepcopy(TASK_DEFAULTS["ShadowHandOpenAI_FF"])
@@ -270,6 +271,15 @@ class SimConfig:
             task_config_ = self._config.get("task", {})
         self._task_config = task_config_
         self._config.setdefault("task", self._task_config)
+        self._sanitize_device()
+
+    def _sanitize_device(self) -> None:
+        """cfg/config.yaml:22-26 spells the device 'gpu' / 'cpu' + device_id; the reference rewrites it from the task's
+        pipeline flag before any task reads it (sim_config.py:152-163).  Torch spellings pass through."""
+        dev = self._config.get("sim_device")
+        if dev in ("gpu", "cpu"):
+            gpu_pipeline = self._task_config.get("sim", {}).get("use_gpu_pipeline", dev == "gpu")
+            self._config["sim_device"] = f"cuda:{self._config.get('device_id', 0)}" if gpu_pipeline else "cpu"
 
     @property
     def config(self) -> Dict[str, Any]:
