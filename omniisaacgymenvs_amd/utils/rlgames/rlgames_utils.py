@@ -153,3 +153,44 @@ class RLGPUAlgoObserver:
             self.writer.add_scalar("scores/mean", mean_scores, frame)
             self.writer.add_scalar("scores/iter", mean_scores, epoch_num)
             self.writer.add_scalar("scores/time", mean_scores, total_time)
+
+
+# rl_games' two registries, as far as rlgames_train.py:68-70 uses them: the names are kept so that
+# ``env_configurations.register("rlgpu", {"vecenv_type": "RLGPU", "env_creator": lambda **kwargs: env})`` reads the same.
+class _EnvConfigurations:
+    def __init__(self):
+        self.configurations = {}
+
+    def register(self, name, config):
+        self.configurations[name] = config
+
+
+env_configurations = _EnvConfigurations()
+
+
+class RLGPUEnv:
+    """The rl_games vec-env adapter over ``VecEnvRLGames`` (rlgames_utils.py:99-124): same five methods, same
+    ``get_env_info`` keys.  ``vecenv.IVecEnv`` is an interface-only base class in rl_games; without it this is a plain class."""
+
+    def __init__(self, config_name, num_actors, **kwargs):
+        self.env = env_configurations.configurations[config_name]["env_creator"](**kwargs)
+
+    def step(self, action):
+        return self.env.step(action)
+
+    def reset(self):
+        return self.env.reset()
+
+    def get_number_of_agents(self):
+        # the reference forwards to the omni.isaac.gym base class (not in its tree); one agent per env for every task here
+        get = getattr(self.env, "get_number_of_agents", None)
+        return get() if get is not None else 1
+
+    def get_env_info(self):
+        info = {"action_space": self.env.action_space, "observation_space": self.env.observation_space}
+        if self.env.num_states > 0:
+            info["state_space"] = self.env.state_space
+            print(info["action_space"], info["observation_space"], info["state_space"])
+        else:
+            print(info["action_space"], info["observation_space"])
+        return info

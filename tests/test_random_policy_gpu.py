@@ -30,3 +30,23 @@ def test_anymal_terrain_refuses_graph():
 def test_main_parses_the_command_line(capsys):
     assert rp.main(["task=Cartpole", "num_envs=128", "--frames", "5"]) == 0
     assert "5 frames of 128 envs" in capsys.readouterr().out
+
+
+def test_rlgpu_env_adapter():
+    """rlgames_train.py:68-70's registration, then the five methods rl_games calls."""
+    from omniisaacgymenvs_amd.utils.rlgames.rlgames_utils import RLGPUEnv, env_configurations
+    from helpers import make_task
+
+    env, task = make_task("ShadowHandOpenAI_FF", 128)
+    env_configurations.register("rlgpu", {"vecenv_type": "RLGPU", "env_creator": lambda **kwargs: env})
+    vec = RLGPUEnv("rlgpu", 128)
+    info = vec.get_env_info()
+    assert set(info) == {"action_space", "observation_space", "state_space"}
+    assert info["action_space"].shape == (20,) and info["observation_space"].shape == (42,) and info["state_space"].shape == (187,)
+    assert vec.get_number_of_agents() == 1
+    obs = vec.reset()
+    obs, rew, done, extras = vec.step(torch.zeros(128, 20, device=task.rl_device))
+    assert obs["obs"].shape == (128, 42) and obs["states"].shape == (128, 187) and rew.shape == done.shape == (128,)
+    env2, _ = make_task("Ant", 64)
+    env_configurations.register("rlgpu", {"vecenv_type": "RLGPU", "env_creator": lambda **kwargs: env2})
+    assert set(RLGPUEnv("rlgpu", 64).get_env_info()) == {"action_space", "observation_space"}
