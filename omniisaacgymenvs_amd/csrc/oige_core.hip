@@ -11,6 +11,7 @@
 // `emit` into their reset stage, so a steady-state step only adds the tiny `scan` launch.
 #include "oige_common.hpp"
 #include "oige_scan.hpp"
+#include "oige_tile.hpp"
 
 namespace oige {
 
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restri
   const int64_t per = n4 / streams;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= per) return;
-  for (int s = 0; s < streams; ++s) dst[s * per + i] = src[s * per + i];
+  for (int s = 0; s < streams; ++s)
+    st4_stream(reinterpret_cast<float*>(dst + s * per + i), ld4_stream(reinterpret_cast<const float*>(src + s * per + i)));
 }
 
 int launch_count_flags(const int64_t* flags, int64_t n, int32_t* ws, hipStream_t stream) {

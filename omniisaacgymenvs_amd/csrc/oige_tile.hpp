@@ -9,6 +9,29 @@
 
 namespace oige {
 
+// Streaming 16-byte global accesses: every tile run is read once or written once per step, so the loads and stores carry
+// the non-temporal hint (`global_load/store_dwordx4 ... nt`).  Measured on the Ant post kernel at 1 M envs: 113 us plain,
+// 101 us nt loads, 102 us nt stores, 92.6 us both (5.15 -> 6.3 TB/s).  -DOIGE_PLAIN_LOAD / -DOIGE_PLAIN_STORE: A/B builds.
+typedef float v4f_native __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_stream(const float* p) {
+#ifndef OIGE_PLAIN_LOAD
+  const v4f_native v = __builtin_nontemporal_load(reinterpret_cast<const v4f_native*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *reinterpret_cast<const float4*>(p);
+#endif
+}
+__device__ __forceinline__ void st4_stream(float* p, const float4 t) {
+#ifndef OIGE_PLAIN_STORE
+  v4f_native v;
+  v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+  __builtin_nontemporal_store(v, reinterpret_cast<v4f_native*>(p));
+#else
+  *reinterpret_cast<float4*>(p) = t;
+#endif
+}
+
+
 // NT = threads that share the tile (64: one wave; 128 / 256: the waves of one workgroup split every run)
 template <int K, int NT = WAVE>
 struct Chunk {
@@ -30,13 +53,13 @@ __device__ __forceinline__ void load_chunk(Chunk<K, NT>& c, const float* __restr
     const int e = 4 * f;
     if (FULL) {
       if (Chunk<K, NT>::EXACT || f < Chunk<K, NT>::NF4)
-        c.v[it] = *reinterpret_cast<const float4*>(src + e);
+        c.v[it] = ld4_stream(src + e);
       else
         c.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (e + 3 < valid) {
-        t = *reinterpret_cast<const float4*>(src + e);
+        t = ld4_stream(src + e);
       } else {
         if (e + 0 < valid) t.x = src[e + 0];
         if (e + 1 < valid) t.y = src[e + 1];
@@ -85,10 +108,10 @@ __device__ __forceinline__ void store_tile(const float* __restrict__ tile, float
     const int e = 4 * f;
     if (FULL) {
       if ((NF4 % NT) == 0 || f < NF4)
-        *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(tile + e);
+        st4_stream(dst + e, *reinterpret_cast<const float4*>(tile + e));
     } else if (f < NF4) {
       if (e + 3 < valid) {
-        *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(tile + e);
+        st4_stream(dst + e, *reinterpret_cast<const float4*>(tile + e));
       } else {
         if (e + 0 < valid) dst[e + 0] = tile[e + 0];
         if (e + 1 < valid) dst[e + 1] = tile[e + 1];
@@ -125,7 +148,7 @@ __device__ __forceinline__ void wg_load_chunk(WgChunk<K, NT, TE>& c, const float
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (f < WgChunk<K, NT, TE>::NF4) {
       if (FULL || e + 3 < valid) {
-        t = *reinterpret_cast<const float4*>(src + e);
+        t = ld4_stream(src + e);
       } else {
         if (e + 0 < valid) t.x = src[e + 0];
         if (e + 1 < valid) t.y = src[e + 1];
@@ -165,7 +188,7 @@ __device__ __forceinline__ void wg_store_tile(const float* __restrict__ tile, fl
     const int e = 4 * f;
     if (f >= NF4) continue;
     if (FULL || e + 3 < valid) {
-      *reinterpret_cast<float4*>(dst + e) = *reinterpret_cast<const float4*>(tile + e);
+      st4_stream(dst + e, *reinterpret_cast<const float4*>(tile + e));
     } else {
       if (e + 0 < valid) dst[e + 0] = tile[e + 0];
       if (e + 1 < valid) dst[e + 1] = tile[e + 1];
