@@ -483,7 +483,7 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
         v.w = v.w + (2.0f * uu[3] - 1.0f) * sc.w;
       }
 #endif
-      *reinterpret_cast<float4*>(a.b.obs_buf + off) = v;
+      st4_stream(a.b.obs_buf + off, v);  // write-once stream: non-temporal (oige_tile.hpp)
     }
   }
 }
@@ -634,7 +634,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
           v.w = v.w + (2.0f * uu[3] - 1.0f) * nscale;
         }
 #endif
-        *reinterpret_cast<float4*>(a.b.obs_buf + off) = v;
+        st4_stream(a.b.obs_buf + off, v);  // write-once stream: non-temporal (oige_tile.hpp)
       }
       cursor_advance(fe, fk, 7, 11, AP4);  // the wave's next chunk: +4 * 64 float4 = 7 * 35 + 11
     }
