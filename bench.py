@@ -716,9 +716,25 @@ def cpu_baseline(task_name: str, n: int, budget_s: float = 10.0):
         if (el > budget_s and k >= 20) or el > 3 * budget_s:
             break
     dt = (time.perf_counter() - t0) / k
+    cores = torch.get_num_threads()
+    # the same step on ONE thread (SURVEY.md 8d asks for both figures): a short sample, at most ~3 s
+    torch.set_num_threads(1)
+    try:
+        step()
+        t1 = time.perf_counter()
+        k1 = 0
+        while True:
+            step()
+            k1 += 1
+            if time.perf_counter() - t1 > 2.0 or k1 >= 20:
+                break
+        dt1 = (time.perf_counter() - t1) / k1
+    finally:
+        torch.set_num_threads(cores)
     return {
-        "value": n / dt, "unit": "env-steps/s", "cores": torch.get_num_threads(), "kind": "port",
+        "value": n / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
         "sample": f"{task_name} oracle (CPU torch restatement of the reference) pre+post, {n} envs, {k} steps, {dt*1e3:.1f} ms/step",
+        "value_1_thread": n / dt1,
     }
 
 
