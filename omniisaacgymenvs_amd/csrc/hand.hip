@@ -488,15 +488,17 @@ __device__ __forceinline__ void allegro_post_tile(const HandPost& a, float* __re
       reset_in = a.b.reset_buf[env];
       reset_goal_in = a.b.reset_goal_buf[env];
       successes = a.b.successes[env];
-      const float4* ar = reinterpret_cast<const float4*>(a.b.actions + env * AD);  // torch.sum(actions**2, dim=-1) (:493)
+      if (!do_obs) {  // split stages: no tile to take the actions from
+        const float4* ar = reinterpret_cast<const float4*>(a.b.actions + env * AD);  // torch.sum(actions**2, dim=-1) (:493)
 #pragma unroll
-      for (int k = 0; k < AD / 4; ++k) {
-        const float4 v = ar[k];
-        const float s0 = v.x * v.x, s1 = v.y * v.y, s2 = v.z * v.z, s3 = v.w * v.w;
-        action_penalty = k == 0 ? s0 : action_penalty + s0;
-        action_penalty += s1;
-        action_penalty += s2;
-        action_penalty += s3;
+        for (int k = 0; k < AD / 4; ++k) {
+          const float4 v = ar[k];
+          const float s0 = v.x * v.x, s1 = v.y * v.y, s2 = v.z * v.z, s3 = v.w * v.w;
+          action_penalty = k == 0 ? s0 : action_penalty + s0;
+          action_penalty += s1;
+          action_penalty += s2;
+          action_penalty += s3;
+        }
       }
     }
   }
@@ -539,6 +541,18 @@ __device__ __forceinline__ void allegro_post_tile(const HandPost& a, float* __re
                              gpos.x, gpos.y, gpos.z, grot.w, grot.x, grot.y, grot.z, rel.w, rel.x, rel.y, rel.z};
 #pragma unroll
       for (int k = 0; k < 18; ++k) r[k] = blk[k];
+    }
+  }
+
+  if (do_obs && do_metrics) {
+    // torch.sum(actions**2, dim=-1) (:493) from the action columns the tile already holds, same left-to-right order: a second
+    // pass over a.b.actions in HBM would re-read 64 B/env that the streaming (non-temporal) chunk load did not leave in cache
+    __syncthreads();  // single-wave workgroup: B's cross-lane LDS writes visible
+    const float* ar = tile + lane * OW + C_ACT;
+#pragma unroll
+    for (int k = 0; k < AD; ++k) {
+      const float sq = ar[k] * ar[k];
+      action_penalty = k == 0 ? sq : action_penalty + sq;
     }
   }
 
