@@ -295,9 +295,12 @@ struct LocoPre {
 };
 
 // reset_idx for env `i` landing in compacted row `k` (locomotion.py:133-158)
-template <int D>
+// STAGE: the DOF rows go to the caller instead of HBM (dof_pos into the LDS row `stage_pos`, dof_vel into `qv_out`), which then
+// writes the group's compacted rows as one lane-linear run
+template <int D, bool STAGE = false>
 __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const oige_locomotion_buffers& b,
-                                          const oige_locomotion_reset_io& r, int64_t i, int64_t k) {
+                                          const oige_locomotion_reset_io& r, int64_t i, int64_t k,
+                                          float* __restrict__ stage_pos = nullptr, float* __restrict__ qv_out = nullptr) {
   // the 2*D uniform draws: [0,D) -> dof_pos (1st torch.rand, :137), [D,2D) -> dof_vel (2nd, :139)
   float u[2 * D];
   if (r.u_pos != nullptr) {
@@ -326,7 +329,13 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
     qp[j] = tensor_clamp(r.initial_dof_pos[i * D + j] + dp, p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :138
     qv[j] = 0.2f * u[D + j] + (-0.1f);
   }
-  if (D % 4 == 0 && aligned16(r.dof_pos_out) && aligned16(r.dof_vel_out)) {  // whole rows as 16-byte stores
+  if (STAGE) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      stage_pos[j] = qp[j];
+      qv_out[j] = qv[j];
+    }
+  } else if (D % 4 == 0 && aligned16(r.dof_pos_out) && aligned16(r.dof_vel_out)) {  // whole rows as 16-byte stores
 #pragma unroll
     for (int c = 0; c < D / 4; ++c) {
       reinterpret_cast<float4*>(r.dof_pos_out + k * D)[c] = make_float4(qp[4 * c], qp[4 * c + 1], qp[4 * c + 2], qp[4 * c + 3]);
@@ -416,7 +425,32 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
   const int cnt = group_offsets[g + 1] - k0;
   if (flagged) s_list[(int)(k - k0)] = (int)threadIdx.x;
   __syncthreads();
-  if ((int)threadIdx.x < cnt) reset_env<D>(a.p, a.b, a.r, g * GROUP + s_list[threadIdx.x], (int64_t)k0 + threadIdx.x);
+  // Rows that are not a whole number of float4 (Humanoid: 21 floats) would leave each lane walking its own 84-byte row with
+  // scalar stores; the group's compacted rows are ONE contiguous run of cnt * D floats, so they are staged through LDS and
+  // written lane-linearly, dof_pos then dof_vel through the same buffer (Ant's 32-byte rows are two float4 per lane, already
+  // contiguous across lanes).
+  constexpr bool STAGE = (D % 4) != 0;
+  __shared__ float s_rows[STAGE ? GROUP * D : 1];
+  const bool mine = (int)threadIdx.x < cnt;
+  if (!STAGE) {
+    if (mine) reset_env<D>(a.p, a.b, a.r, g * GROUP + s_list[threadIdx.x], (int64_t)k0 + threadIdx.x);
+  } else if (cnt > 0) {  // cnt is uniform over the workgroup: the barriers below are reached by all of it or none
+    float qv[D];
+    if (mine)
+      reset_env<D, true>(a.p, a.b, a.r, g * GROUP + s_list[threadIdx.x], (int64_t)k0 + threadIdx.x, s_rows + threadIdx.x * D, qv);
+    __syncthreads();
+    const int run = cnt * D;
+    float* dst = a.r.dof_pos_out + (int64_t)k0 * D;
+    for (int e = threadIdx.x; e < run; e += GROUP) dst[e] = s_rows[e];
+    __syncthreads();
+    if (mine) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) s_rows[threadIdx.x * D + j] = qv[j];
+    }
+    __syncthreads();
+    dst = a.r.dof_vel_out + (int64_t)k0 * D;
+    for (int e = threadIdx.x; e < run; e += GROUP) dst[e] = s_rows[e];
+  }
   if (g == 0 && threadIdx.x == 0) *a.r.count = (int64_t)group_offsets[G];
 }
 
