@@ -217,16 +217,23 @@ __device__ __forceinline__ void nh_draws(const NhPre& a, int64_t i, float (&u)[N
   }
 }
 
-// reset_idx for env i landing in compacted row k: view rows, target row, flags
+// reset_idx for env i landing in compacted row k: view rows, target row, flags.  `stage` != nullptr (the pre kernel): the new
+// joint positions go to that LDS row only; the caller writes dof_pos_out / dof_vel_out as lane-linear runs and its target walk
+// takes the row from LDS (a lane walking its own D-float row with scalar stores, three times over, was the pre kernel's hot spot)
 template <int D>
-__device__ __forceinline__ void nh_reset_rows(const NhPre& a, int64_t i, int64_t k, const float (&u)[NMAX + 2]) {
+__device__ __forceinline__ void nh_reset_rows(const NhPre& a, int64_t i, int64_t k, const float (&u)[NMAX + 2],
+                                              float* __restrict__ stage = nullptr) {
   const oige_newhand_cabinet_params& p = a.p;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     const float pos = tensor_clamp(p.default_dof_pos[j] + 0.25f * (u[j] - 0.5f), p.dof_lower[j], p.dof_upper[j]);
-    a.r.dof_pos_out[k * D + j] = pos;
-    a.r.dof_vel_out[k * D + j] = 0.0f;
-    a.b.dof_targets[i * D + j] = pos;
+    if (stage) {
+      stage[j] = pos;
+    } else {
+      a.r.dof_pos_out[k * D + j] = pos;
+      a.r.dof_vel_out[k * D + j] = 0.0f;
+      a.b.dof_targets[i * D + j] = pos;
+    }
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   *reinterpret_cast<float4*>(a.r.cabinet_dof_pos_out + k * 4) = z4;
@@ -247,7 +254,8 @@ __device__ __forceinline__ void nh_reset_rows(const NhPre& a, int64_t i, int64_t
 template <int D, int A>
 __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre a) {
   __shared__ int lds4[GROUP_TILES];
-  __shared__ int s_list[GROUP];
+  __shared__ int s_list[GROUP], s_rank[GROUP];
+  __shared__ float s_rows[GROUP * D];  // new joint positions of the group's reset envs, compacted row order
   __shared__ float s_lo[D], s_hi[D], s_rate[D];
   __shared__ int s_inv[D];  // joint -> action column, -1: not actuated
   const oige_newhand_cabinet_params& p = a.p;
@@ -262,6 +270,7 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   const int32_t k0 = group_offsets[g];
   const int cnt = group_offsets[g + 1] - k0;
   if (flagged) s_list[(int)(k - k0)] = tid;
+  s_rank[tid] = flagged ? (int)(k - k0) : -1;
 #pragma unroll
   for (int j = 0; j < D; ++j)
     if (tid == j) {
@@ -278,13 +287,22 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   }
   __syncthreads();
 
-  if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env; its target row goes to global memory
+  if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env; its new joint row goes to LDS row j
     const int64_t i = g * GROUP + s_list[tid];
     float u[NMAX + 2];
     nh_draws<D>(a, i, u);
-    nh_reset_rows<D>(a, i, (int64_t)k0 + tid, u);
+    nh_reset_rows<D>(a, i, (int64_t)k0 + tid, u, s_rows + tid * D);
   }
-  __syncthreads();  // the reset envs' new target rows are visible to the whole workgroup
+  __syncthreads();  // the reset envs' new rows are visible to the whole workgroup
+  {  // dof_pos_out / dof_vel_out rows k0 .. k0 + cnt: one contiguous run each, written lane-linearly
+    const int run = cnt * D;
+    float* dp = a.r.dof_pos_out + (int64_t)k0 * D;
+    float* dv = a.r.dof_vel_out + (int64_t)k0 * D;
+    for (int e = tid; e < run; e += GROUP) {
+      dp[e] = s_rows[e];
+      dv[e] = 0.0f;
+    }
+  }
 
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
   const bool clampa = a.flags & OIGE_PRE_CLAMP_ACTIONS;
@@ -332,6 +350,8 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
         const int ee = e + c;
         if (ee >= total) continue;
         const int il = ee / D, jj = ee - il * D;
+        const int rk = s_rank[il];
+        if (rk >= 0) tv[c] = s_rows[rk * D + jj];  // dof_targets[env_ids] = pos (reset_idx), then this step's integration
         const int ja = s_inv[jj];
         if (ja < 0) continue;
         float av = a.actions_in[(g * GROUP + il) * A + ja];
