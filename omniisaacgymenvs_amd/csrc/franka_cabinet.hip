@@ -196,14 +196,17 @@ __device__ __forceinline__ void franka_draws(const FrankaPre& a, int64_t i, floa
 }
 
 // reset_idx (:375-414) for env i landing in compacted row k; pos[] = its new joint positions
-template <int FD>
+// DOF_ROWS = false (the pre kernel): the caller writes the dof_pos_out / dof_vel_out rows of its group as one lane-linear run
+template <int FD, bool DOF_ROWS = true>
 __device__ __forceinline__ void franka_reset_rows(const FrankaPre& a, int64_t i, int64_t k, const float (&u)[FMAX], float (&pos)[FMAX]) {
   const oige_franka_cabinet_params& p = a.p;
 #pragma unroll
   for (int j = 0; j < FD; ++j) {
     pos[j] = tensor_clamp(p.default_dof_pos[j] + 0.25f * (u[j] - 0.5f), p.dof_lower[j], p.dof_upper[j]);  // :380-385
-    a.r.dof_pos_out[k * FD + j] = pos[j];
-    a.r.dof_vel_out[k * FD + j] = 0.0f;
+    if (DOF_ROWS) {
+      a.r.dof_pos_out[k * FD + j] = pos[j];
+      a.r.dof_vel_out[k * FD + j] = 0.0f;
+    }
   }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   *reinterpret_cast<float4*>(a.r.cabinet_dof_pos_out + k * CD) = z4;  // :393-398
@@ -254,11 +257,21 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
     const int64_t i = g * GROUP + il;
     float u[FMAX], pos[FMAX];
     franka_draws(a, i, u);
-    franka_reset_rows<FD>(a, i, (int64_t)k0 + tid, u, pos);
+    franka_reset_rows<FD, false>(a, i, (int64_t)k0 + tid, u, pos);
 #pragma unroll
     for (int j = 0; j < FD; ++j) s_pos[il * FD + j] = pos[j];  // franka_dof_targets[env_ids] = pos (:389)
   }
   __syncthreads();
+  {  // view rows k0 .. k0 + cnt of dof_pos_out / dof_vel_out: one contiguous run each, written lane-linearly from s_pos
+    const int run = cnt * FD;
+    float* dp = a.r.dof_pos_out + (int64_t)k0 * FD;
+    float* dv = a.r.dof_vel_out + (int64_t)k0 * FD;
+    for (int e = tid; e < run; e += GROUP) {
+      const int r = e / FD, j = e - r * FD;
+      dp[e] = s_pos[s_list[r] * FD + j];
+      dv[e] = 0.0f;
+    }
+  }
 
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
   const int total = (int)envs_here * FD;
