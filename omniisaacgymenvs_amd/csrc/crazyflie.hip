@@ -380,8 +380,7 @@ int oige_crazyflie_pre_physics(const oige_crazyflie_params* params, const float*
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(crazyflie_count_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   if (int rc = check_launch("crazyflie_count_kernel")) return rc;
-  if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-  if (int rc = launch_scan_groups(num_envs, a.b.target_workspace, s)) return rc;
+  if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.target_workspace, s)) return rc;
   hipLaunchKernelGGL(crazyflie_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   if (int rc = check_launch("crazyflie_pre_kernel")) return rc;
   hipLaunchKernelGGL(crazyflie_extras_kernel, dim3(1), dim3(CE * WAVE), 0, s, a);

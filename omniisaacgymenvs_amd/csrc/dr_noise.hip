@@ -180,8 +180,7 @@ int oige_dr_noise_count(const oige_noise_args* args, int64_t num_envs, oige_stre
     hipLaunchKernelGGL(dr_noise_count_kernel, dim3((unsigned)G), dim3(GROUP), 0, st, *args, num_envs);
     if (int rc = check_launch("dr_noise_count_kernel")) return rc;
   }
-  if (int rc = launch_scan_groups(num_envs, args->reset_workspace, st)) return rc;
-  return launch_scan_groups(num_envs, args->interval_workspace, st);
+  return launch_scan_groups2(num_envs, args->reset_workspace, args->interval_workspace, st);
 }
 
 int oige_dr_noise_apply(const oige_noise_args* args, int64_t num_envs, oige_stream_t stream) {

@@ -1159,8 +1159,7 @@ static int hand_pre_physics(const oige_hand_params* params, const float* actions
     if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
     if (int rc = launch_count_flags(a.b.reset_goal_buf, num_envs, a.b.goal_workspace, s)) return rc;
   }
-  if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-  if (int rc = launch_scan_groups(num_envs, a.b.goal_workspace, s)) return rc;
+  if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.goal_workspace, s)) return rc;
   if (is_allegro(params))
     hipLaunchKernelGGL((hand_pre_kernel<OIGE_ALLEGRO_DOFS, OIGE_ALLEGRO_DOFS>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
   else

@@ -341,8 +341,7 @@ int oige_ingenuity_pre_physics(const oige_ingenuity_params* params, const float*
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(ingenuity_count_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   if (int rc = check_launch("ingenuity_count_kernel")) return rc;
-  if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-  if (int rc = launch_scan_groups(num_envs, a.b.target_workspace, s)) return rc;
+  if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.target_workspace, s)) return rc;
   hipLaunchKernelGGL(ingenuity_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   return check_launch("ingenuity_pre_kernel");
 }

@@ -52,6 +52,7 @@ inline int64_t workspace_ints(int64_t n) { return padded_tiles(n) + num_groups(n
 // launches the count (optional) and scan kernels on `stream` (oige_core.hip)
 int launch_count_flags(const int64_t* flags, int64_t n, int32_t* ws, hipStream_t stream);
 int launch_scan_groups(int64_t n, int32_t* ws, hipStream_t stream);
+int launch_scan_groups2(int64_t n, int32_t* ws_a, int32_t* ws_b, hipStream_t stream);  // two workspaces, one launch
 
 // ---------------------------------------------------------------- device helpers
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
