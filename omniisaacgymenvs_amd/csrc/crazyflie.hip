@@ -260,6 +260,9 @@ __global__ __launch_bounds__(CE * WAVE) void crazyflie_extras_kernel(const CfPre
   const int k = threadIdx.x >> 6, lane = lane_id();
   const int64_t G = num_groups(a.n);
   double acc = 0.0;
+  // same left-to-right sum per lane; unrolled so that the independent loads of eight iterations are in flight together
+  // (one wave, 64 dependent load-add rounds at 1 M envs: this launch is pure latency)
+#pragma unroll 8
   for (int64_t i = lane; i < G; i += WAVE) acc += (double)a.b.reduce_workspace[i * CE + k];
 #pragma unroll
   for (int off = WAVE / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, WAVE);

@@ -601,7 +601,8 @@ __global__ __launch_bounds__(1024) void hand_finalize_kernel(const float* __rest
                                                              float* __restrict__ cons, float av, float one_minus_av) {
   __shared__ double s_n[1024 / WAVE], s_f[1024 / WAVE];
   double n = 0.0, f = 0.0;
-  for (int64_t i = threadIdx.x; i < tiles; i += 1024) {
+#pragma unroll 8
+  for (int64_t i = threadIdx.x; i < tiles; i += 1024) {  // same order per thread; the unrolled loads overlap
     n += (double)partials[2 * i];
     f += (double)partials[2 * i + 1];
   }
