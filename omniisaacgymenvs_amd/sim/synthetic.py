@@ -156,6 +156,11 @@ class SyntheticArticulationView:
         if joint_indices is not None:
             # all envs, a subset of joints (in_hand_manipulation.py:360-362): keep the (N, len(joint_indices)) block
             self.joint_position_targets_subset = (positions, joint_indices)
+        elif self.apply_resets is False and (indices is None or (count is None and indices.shape[0] == self.count)):
+            # benchmark mode (reset hand-overs dropped), all envs: keep a reference, like set_joint_efforts.  PhysX consumes
+            # the caller's tensor; an N*D copy or index_put here bills the stand-in's work to the task step (50 us per step
+            # on flat Anymal at 1 M envs).  Not in the functional modes: a later reset scatter would write through the alias.
+            self.joint_position_targets = positions
         elif indices is None:
             self.joint_position_targets.copy_(positions)
         else:
