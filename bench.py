@@ -27,7 +27,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch  # noqa: E402
 
@@ -49,7 +48,7 @@ ANYMAL_POST_BYTES = 512 + 560 + 913     # state + 280 int16 gathers + obs/flags/
 # ---------------------------------------------------------------------------- per-task adapters
 class LocomotionBench:
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.name = name
@@ -105,7 +104,7 @@ class HandBench:
     """C4: ShadowHandOpenAI_FF (openai obs + asymmetric full_state states + goal-rotation reward) with DR noise."""
 
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
         from omniisaacgymenvs_amd.utils.config import TASK_DEFAULTS
 
@@ -201,7 +200,7 @@ class AnymalBench:
     """C5 per-GPU shard: AnymalTerrain height-scan obs + 11-term reward + in-step reset."""
 
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.env, self.task = make_task("AnymalTerrain", n, device=dev, seed=seed)
@@ -267,7 +266,7 @@ class AllegroHandBench:
     """AllegroHand, `full` obs(72) + goal-rotation reward + resets (the YAML has no DR section)."""
 
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.env, self.task = make_task("AllegroHand", n, device=dev, seed=seed)
@@ -319,7 +318,7 @@ class QuadcopterBench:
     """Quadcopter obs(21) + inverse-quadratic reward + non-sticky done, targets / thrust integration."""
 
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.env, self.task = make_task("Quadcopter", n, device=dev, seed=seed)
@@ -368,7 +367,7 @@ class BallBalanceBench:
     """BallBalance obs(24) + reward + sticky done, position-target integration."""
 
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.env, self.task = make_task("BallBalance", n, device=dev, seed=seed)
@@ -418,7 +417,7 @@ class IngenuityBench:
     """Ingenuity obs(13) + reward + done, reset + set_targets compactions, thrust vectors."""
 
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.env, self.task = make_task("Ingenuity", n, device=dev, seed=seed)
@@ -466,7 +465,7 @@ class CrazyflieBench:
     """Crazyflie obs(18) + 4-term reward + 8 episode sums + done; motor filter, two compactions, extras."""
 
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.env, self.task = make_task("Crazyflie", n, device=dev, seed=seed)
@@ -514,7 +513,7 @@ class FrankaCabinetBench:
     """FrankaCabinet grasp transforms + obs(23) + 8-term reward + sticky done; target integration, resets."""
 
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.env, self.task = make_task(name, n, device=dev, seed=seed)
@@ -572,7 +571,7 @@ class NewhandCabinetBench:
     """the fork's five-finger cabinet tasks (10 keypoints, obs(2D+5), reward, sticky done [+ terminate])."""
 
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.env, self.task = make_task(name, n, device=dev, seed=seed)
@@ -628,7 +627,7 @@ class AnymalFlatBench:
     """Anymal on flat ground (obs 48, 6-term reward, non-sticky done, position targets)."""
 
     def __init__(self, name, n, dev, seed):
-        from helpers import make_task
+        from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.env, self.task = make_task("Anymal", n, device=dev, seed=seed)
@@ -674,7 +673,6 @@ class AnymalFlatBench:
 
 ADAPTERS = {"TomoDJnewhandCabinet": NewhandCabinetBench, "TomoDJnewhandTendonCabinet": NewhandCabinetBench, "TomoSPCnewhandCabinet": NewhandCabinetBench, "TomoDJCabinet": FrankaCabinetBench, "TomoSPCCabinet": FrankaCabinetBench, "FrankaCabinet": FrankaCabinetBench, "Crazyflie": CrazyflieBench, "Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
 DEFAULT_ENVS = {"TomoDJnewhandCabinet": 1 << 19, "TomoDJnewhandTendonCabinet": 1 << 19, "TomoSPCnewhandCabinet": 1 << 19, "TomoDJCabinet": 1 << 20, "TomoSPCCabinet": 1 << 20, "FrankaCabinet": 1 << 20, "Crazyflie": 1 << 20, "Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
-CPU_ENVS = {"TomoDJnewhandCabinet": 1 << 17, "TomoDJnewhandTendonCabinet": 1 << 17, "TomoSPCnewhandCabinet": 1 << 17, "TomoDJCabinet": 1 << 18, "TomoSPCCabinet": 1 << 18, "FrankaCabinet": 1 << 18, "Crazyflie": 1 << 18, "Ingenuity": 1 << 18, "BallBalance": 1 << 18, "Quadcopter": 1 << 18, "AllegroHand": 1 << 18, "Anymal": 1 << 18, "Ant": 1 << 18, "Humanoid": 1 << 17, "ShadowHand": 1 << 16, "AnymalTerrain": 1 << 15}
 
 
 def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:
@@ -738,6 +736,98 @@ def cpu_baseline(task_name: str, n: int, budget_s: float = 10.0):
     }
 
 
+class DryBench:
+    """``--task _dry``: no HIP, no GPU -- CPU tensors and a trivial step, so the launcher, the rendezvous, the statistics
+    all-reduce and the max-over-ranks timing of the N>1 path can run where there is no GPU (tests/test_bench_launcher_cpu.py).
+    Its line is marked ``"data": "dry-run"``: it measures nothing."""
+
+    def __init__(self, name, n, dev, seed):
+        import types
+
+        g = torch.Generator().manual_seed(seed)
+        self.task = types.SimpleNamespace(rew_buf=torch.randn(n, generator=g), reset_buf=(torch.rand(n, generator=g) < 0.1).long(),
+                                          progress_buf=torch.randint(0, 1000, (n,), generator=g))
+        self.post_bytes, self.kernel, self.extra_cfg = 0, "none", {}
+        self.workload = f"dry run of the launcher / collective path, {n} CPU rows per rank, no HIP kernels"
+
+    def pre(self):
+        self.task.progress_buf += 1
+
+    def post(self):
+        self.task.rew_buf *= 1.0
+
+    def resets(self):
+        return int(self.task.reset_buf.sum())
+
+
+ADAPTERS["_dry"] = DryBench
+DEFAULT_ENVS["_dry"] = 1 << 12
+
+
+def _free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n_ranks: int, argv) -> int:
+    """``python bench.py --gpus N`` without a launcher around it: start N ranks of this script under
+    ``python -m torch.distributed.run`` (the reference's launch, README.md:292-314), one process per GPU, and return the
+    launcher's exit code.  The parent has not touched the GPU (``device_count`` does not initialise it) and execs nothing: the
+    ranks are children.  With fewer visible GPUs than ranks (a rehearsal on a one-GPU box) the ranks share devices, which
+    RCCL cannot do, so the statistics collective falls back to gloo unless OIGE_DIST_BACKEND says otherwise."""
+    import subprocess
+
+    env = os.environ.copy()
+    if "OIGE_DIST_BACKEND" not in env and torch.cuda.device_count() < n_ranks:
+        env["OIGE_DIST_BACKEND"] = "gloo"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    print("[bench] launching", " ".join(cmd), f"(backend {env.get('OIGE_DIST_BACKEND', 'nccl')})", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_rank(dry: bool):
+    """(dist | None, world, rank, device string, backend name) of this rank; per-rank device as rlgames_train.py:114-120."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    gpu = 0
+    if not dry:
+        gpu = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(gpu)
+    dev = "cpu" if dry else f"cuda:{gpu}"
+    if world == 1:
+        return None, 1, 0, dev, "none"
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # OIGE_DIST_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, the
+    # statistics all-reduce runs over gloo on the host); the real runs use RCCL (backend "nccl" on ROCm)
+    backend = "gloo" if dry else os.environ.get("OIGE_DIST_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group(backend="nccl", device_id=torch.device(dev))
+    else:
+        dist.init_process_group(backend=backend)
+    return dist, world, rank, dev, backend
+
+
+def reduce_timing(dist, elapsed: float, dev: str, backend: str) -> dict:
+    """MAX over ranks of the timed region (the bench contract) + the spread and a head count of the ranks that took part."""
+    if dist is None:
+        return {"elapsed": elapsed, "min": elapsed, "max": elapsed, "ranks_seen": 1}
+    on = dev if backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed, -elapsed], dtype=torch.float64, device=on)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ones = torch.ones(1, dtype=torch.int64, device=on)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    hi, neg_lo = t.tolist()
+    return {"elapsed": hi, "min": -neg_lo, "max": hi, "ranks_seen": int(ones.item())}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -748,7 +838,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the whole step as one HIP graph (RLTask.capture_step): the launch-bound regime of the "
-                         "reference's own sizes, e.g. --envs 4096 (not for ShadowHand's DR adapter or AnymalTerrain)")
+                         "reference's own sizes, e.g. --envs 4096 (not for ShadowHand's DR adapter)")
+    ap.add_argument("--no-graph-leg", action="store_true", help="skip the extra graph-replay timing (graph_ms_per_step)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --envs per GPU (default); strong: the one-GPU env count split over the ranks")
     ap.add_argument("--cpu-envs", type=int, default=0)
@@ -756,27 +847,14 @@ def main() -> None:
                     help="PMC-derived HBM bytes per launch of the dominant kernel (profiles/run_profiles.sh) -> roofline.traffic")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # bare `python bench.py --gpus N`: be the launcher
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # OIGE_DIST_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices,
-        # the statistics all-reduce runs over gloo on the host); the real runs use RCCL (backend "nccl" on ROCm)
-        backend = os.environ.get("OIGE_DIST_BACKEND", "nccl")
-        gpu = local_rank % max(torch.cuda.device_count(), 1)
-        torch.cuda.set_device(gpu)
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{gpu}"))
-        else:
-            dist.init_process_group(backend=backend)
-    else:
-        dist = None
-        gpu = 0
-        torch.cuda.set_device(0)
-    dev = f"cuda:{gpu}"
+    dry = args.task == "_dry"
+    dist, world, rank, dev, backend = init_rank(dry)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
 
     from omniisaacgymenvs_amd.utils import distributed as od
 
@@ -790,15 +868,23 @@ def main() -> None:
 
     # HIP events around the post kernel of every timed step.  They are CREATED here: hipEventCreate inside the loop costs
     # ~100 us per step (measured), recording a ready-made one does not.
-    ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if dry:
+        class _NoEvent:
+            def record(self):
+                pass
+
+        ev_pairs = [(_NoEvent(), _NoEvent()) for _ in range(args.steps)]
+        ev_start = [_NoEvent() for _ in range(args.steps)]
+    else:
+        ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     after = getattr(bench, "after_post", lambda: None)
     if args.graph:
         if hasattr(bench, "after_post"):  # HandBench: noise arguments per call, wrapper-side leg
             raise SystemExit(f"--graph: the {args.task} adapter does more than the two task calls per step; "
                              "see tests/test_graph_step_gpu.py for its captured step")
         with contextlib.redirect_stdout(sys.stderr):
-            bench.task.capture_step(bench.actions)  # raises for AnymalTerrain (host-side branch in its step)
+            bench.task.capture_step(bench.actions)
         bench.pre, bench.post = bench.task.replay_step, (lambda: None)
 
     def timed_step(es, e0, e1):
@@ -813,14 +899,14 @@ def main() -> None:
         bench.pre()
         bench.post()
         after()
-    torch.cuda.synchronize()
+    sync()
     # first use of torch's reduction kernels (lazy code-object load) and of the communicator (RCCL sets its rings up
     # lazily): keep both out of the timed region
     t = bench.task
     od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     if args.graph:  # one graph launch per step, nothing else on the stream; events only around the whole loop
         ev_start[0].record()
@@ -834,26 +920,32 @@ def main() -> None:
     # cross-rank exchange, one 40-byte all-reduce over RCCL (utils/distributed.py)
     t = bench.task
     job_stats = od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    sync()
+    timing = reduce_timing(dist, time.perf_counter() - t0, dev, backend)
+    elapsed = timing["elapsed"]
 
-    if args.graph:  # the kernels are nodes of one graph: the whole replayed step stands in for the post kernel (a lower bound)
+    if dry:
+        post_ms = pre_ms = gpu_span_ms = None
+    elif args.graph:  # the kernels are nodes of one graph: the whole replayed step stands in for the post kernel (a lower bound)
         post_ms, pre_ms = ev_start[0].elapsed_time(ev_pairs[-1][1]) / len(ev_pairs), None
     else:
         post_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
         pre_ms = sum(es.elapsed_time(e0) for es, (e0, _) in zip(ev_start, ev_pairs)) / len(ev_pairs)
-    gpu_span_ms = ev_start[0].elapsed_time(ev_pairs[-1][1]) / len(ev_pairs)  # first pre launch -> last post end, per step
-    copy_gbs = measured_copy_gbs(dev, bench.post_bytes * n) if rank == 0 else None
-    achieved = bench.post_bytes * n / (post_ms * 1e-3) / 1e9
+    if not dry:
+        gpu_span_ms = ev_start[0].elapsed_time(ev_pairs[-1][1]) / len(ev_pairs)  # first pre launch -> last post end, per step
+
+    # second leg (default line): the same K steps replayed as ONE HIP graph per step (RLTask.capture_step), so the line
+    # shows what launch gaps and Python marshalling cost next to the eager figure.  Outside the timed region above.
+    graph_ms = graph_note = None
+    if not dry and not args.graph and not args.no_graph_leg:
+        graph_ms, graph_note = graph_leg(bench, args.steps, dist)
+
+    copy_gbs = measured_copy_gbs(dev, bench.post_bytes * n) if rank == 0 and not dry else None
     traffic = None
-    if args.traffic_json and os.path.exists(args.traffic_json):
+    if args.traffic_json and os.path.exists(args.traffic_json) and not dry:
         with open(args.traffic_json) as f:
             rec = json.load(f).get(args.task)
         if rec:  # measured at rec["envs"] envs per launch; the kernels stream, so bytes scale with the env count
@@ -878,22 +970,64 @@ def main() -> None:
             "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "dry-run" if dry else "synthetic",
             "config": cfg,
-            "roofline": {
+            "ranks_seen": timing["ranks_seen"],
+            "rank_ms_per_step": {"min": timing["min"] / args.steps * 1e3, "max": timing["max"] / args.steps * 1e3},
+            "collective_backend": {"nccl": "rccl"}.get(backend, backend),
+        }
+        if graph_ms is not None or graph_note is not None:
+            out["graph_ms_per_step"] = graph_ms
+            out["graph_value"] = None if graph_ms is None else world * n / (graph_ms * 1e-3)
+            if graph_note:
+                out["graph_note"] = graph_note
+        if not dry:
+            achieved = bench.post_bytes * n / (post_ms * 1e-3) / 1e9
+            out["roofline"] = {
                 "bound": "hbm", "kernel": bench.kernel + (" (+ pre_physics: whole replayed graph timed)" if args.graph else ""), "achieved": achieved, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_env": bench.post_bytes, "avg_kernel_ms": post_ms,
                 "pre_physics_ms": pre_ms, "gpu_ms_per_step": gpu_span_ms,
                 "measured_copy_gbs": copy_gbs,
                 "frac_of_measured_copy_12_streams": achieved / copy_gbs["streams_12"],
-            },
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.task, min(n, args.cpu_envs or CPU_ENVS[args.task]))
+            }
+        if not args.no_cpu_baseline and world == 1 and not dry:
+            out["cpu_baseline"] = cpu_baseline(args.task, args.cpu_envs or n)
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def graph_leg(bench, steps: int, dist):
+    """(ms per step, note): ``steps`` replays of the captured whole step, max over ranks; (None, reason) where the
+    adapter's step is more than the two task calls or the task refuses capture."""
+    if hasattr(bench, "graph_capture"):
+        capture, replay = bench.graph_capture, bench.graph_replay
+    elif hasattr(bench, "after_post"):
+        return None, "adapter runs wrapper-side legs outside the two task calls"
+    else:
+        capture, replay = (lambda: bench.task.capture_step(bench.actions)), (lambda: bench.task.replay_step())
+    try:
+        with contextlib.redirect_stdout(sys.stderr):
+            capture()
+    except NotImplementedError as e:
+        return None, str(e)
+    for _ in range(5):
+        replay()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        replay()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    return el / steps * 1e3, None
 
 
 if __name__ == "__main__":

@@ -15,7 +15,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liboige_hip.so")
 SOURCES = ["oige_core.hip", "locomotion.hip", "cartpole.hip", "hand.hip", "anymal_terrain.hip", "dr_noise.hip", "anymal.hip", "quadcopter.hip", "ball_balance.hip", "ingenuity.hip", "crazyflie.hip", "franka_cabinet.hip", "newhand_cabinet.hip", "observer.hip"]
-HEADERS = ["oige_common.hpp", "oige_math.hpp", "oige_tile.hpp", os.path.join("..", "..", "include", "oige_hip.h")]
+
+
+def dependencies():
+    """Every file the library is built from: all of csrc/ (*.hip, *.hpp) and include/*.h -- globbed, so a new header
+    cannot be forgotten in the stale check."""
+    import glob
+
+    inc = os.path.join(HERE, "..", "include")
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.hpp"))
+                  + glob.glob(os.path.join(inc, "*.h")))
+
+
 FLAGS = [
     "--offload-arch=gfx950",
     "-O3",
@@ -39,8 +50,8 @@ def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    deps = dependencies() + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
 
 
 def build_variant(name: str, defines, verbose: bool = True) -> str:

@@ -91,3 +91,16 @@ def initialize_task(config: Dict[str, Any], env, init_sim: bool = True):
     env.set_task(task=task, sim_params=physics, backend="warp" if warp else "torch", init_sim=init_sim,
                  rendering_dt=physics["rendering_dt"])
     return task
+
+
+def make_task(name: str, n: int, device: str = "cuda:0", seed: int = 42, **env_overrides):
+    """``(env, task)`` of ``n`` envs through the reference's own front door: table config -> ``VecEnvRLGames`` ->
+    ``initialize_task(config, env)`` (task_util.py:109-132).  Used by bench.py, smoke() and the tests; oracle-free."""
+    from omniisaacgymenvs_amd.envs.vec_env_rlgames import VecEnvRLGames
+    from omniisaacgymenvs_amd.utils.config import global_config, task_config
+
+    cfg = global_config(sim_device=device, rl_device=device, seed=seed, task_name=name,
+                        task=task_config(name, num_envs=n, **env_overrides))
+    env = VecEnvRLGames(headless=True)
+    task = initialize_task(cfg, env)
+    return env, task

@@ -3,23 +3,11 @@ from __future__ import annotations
 
 import torch
 
-from omniisaacgymenvs_amd.envs.vec_env_rlgames import VecEnvRLGames
-from omniisaacgymenvs_amd.utils.config import SimConfig, global_config, task_config
+from omniisaacgymenvs_amd.utils.task_util import make_task  # noqa: F401  (re-exported for the tests)
 from oracle import locomotion_oracle as lo
 
 # north_star tolerance for fp32 observations and rewards
 RTOL, ATOL = 1e-5, 1e-6
-
-
-def make_task(name: str, n: int, device: str = "cuda:0", seed: int = 42, **env_overrides):
-    """Through the reference's own front door: initialize_task(config, env) (utils/task_util.py:109-132)."""
-    from omniisaacgymenvs_amd.utils.task_util import initialize_task
-
-    cfg = global_config(sim_device=device, rl_device=device, seed=seed, task_name=name,
-                        task=task_config(name, num_envs=n, **env_overrides))
-    env = VecEnvRLGames(headless=True)
-    task = initialize_task(cfg, env)
-    return env, task
 
 
 def oracle_spec(task) -> lo.LocomotionSpec:

@@ -94,3 +94,23 @@ def test_every_entry_point_rejects_null_arguments_without_touching_the_gpu():
         assert msg and len(msg) > 5, name
         checked += 1
     assert checked >= 20
+
+
+def test_stale_check_covers_every_source_and_header():
+    """build.is_stale() must see every file the library is built from (oige_noise.hpp / oige_scan.hpp were
+    missing): every #include "..." under csrc/ resolves to a file in build.dependencies(), and every .hip is compiled."""
+    import glob
+    import re
+
+    from omniisaacgymenvs_amd import build as b
+
+    deps = {os.path.realpath(d) for d in b.dependencies()}
+    hips = sorted(glob.glob(os.path.join(b.CSRC, "*.hip")))
+    assert sorted(os.path.basename(h) for h in hips) == sorted(b.SOURCES)
+    for src in hips + glob.glob(os.path.join(b.CSRC, "*.hpp")):
+        assert os.path.realpath(src) in deps
+        for inc in re.findall(r'#include\s+"([^"]+)"', open(src).read()):
+            cands = [os.path.join(b.CSRC, inc), os.path.join(b.HERE, "..", "include", inc), os.path.join(b.CSRC, os.path.dirname(inc), os.path.basename(inc))]
+            hit = [c for c in cands if os.path.exists(c)]
+            assert hit, (src, inc)
+            assert os.path.realpath(hit[0]) in deps, (src, inc)
