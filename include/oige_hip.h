@@ -61,6 +61,15 @@ int oige_count_flags_i64(const int64_t* flags, int64_t n, int32_t* workspace, oi
 int oige_compact_i64(const int64_t* flags, int64_t n, int32_t* workspace, int64_t* ids_out,
                      int64_t* count_out, oige_stream_t stream);
 
+/* No counterpart in the reference: oige_compact_i64 for callers that cannot allocate (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc) and so have no workspace to pass.  Same kernels, same results;
+ * the workspace is a 320 KiB array inside the library's device image (every GPU the library runs on holds its own copy
+ * until the process ends).  The call allocates and frees nothing.  n <= oige_compact_static_max_envs() (4 194 304);
+ * larger n is rejected with OIGE_EINVAL.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
+ * (two streams, two threads) race -- serialise them, or use oige_compact_i64 with separate workspaces.           */
+int64_t oige_compact_static_max_envs(void);
+int oige_compact_i64_static(const int64_t* flags, int64_t n, int64_t* ids_out, int64_t* count_out, oige_stream_t stream);
+
 /* ------------------------------------------------------------------ locomotion (Ant, Humanoid)
  * Scalars: LocomotionTask.update_config (tasks/shared/locomotion.py:50-65) and
  * post_reset (:162-184); tables: tasks/ant.py:89-93, tasks/humanoid.py:91-121.

@@ -347,6 +347,8 @@ SIGNATURES = {
     "oige_workspace_ints": (C.c_int64, [C.c_int64]),
     "oige_count_flags_i64": (C.c_int, [_P, C.c_int64, _P, _P]),
     "oige_compact_i64": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P]),
+    "oige_compact_static_max_envs": (C.c_int64, []),
+    "oige_compact_i64_static": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "oige_locomotion_post_physics": (C.c_int, [C.POINTER(LocomotionParams), C.POINTER(LocomotionState),
                                                C.POINTER(LocomotionBuffers), C.c_int64, C.c_uint32, _P]),
     "oige_locomotion_pre_physics": (C.c_int, [C.POINTER(LocomotionParams), _P, C.POINTER(LocomotionBuffers),
@@ -493,6 +495,13 @@ def workspace_ints(n: int) -> int:
 def new_workspace(n: int, device) -> torch.Tensor:
     """Zero-initialised int32 reset workspace (tile counts + group offsets)."""
     return torch.zeros(max(workspace_ints(n), 4), dtype=torch.int32, device=device)
+
+
+def compact_static(flags: torch.Tensor, ids_out: torch.Tensor, count_out: torch.Tensor) -> None:
+    """``compact`` without a workspace argument: the library's own per-GPU static scratch (at most
+    ``oige_compact_static_max_envs()`` flags; allocates nothing; calls overlapping on one GPU race)."""
+    check(load().oige_compact_i64_static(ptr(flags), flags.shape[0], ptr(ids_out), ptr(count_out),
+                                         current_stream(flags.device)), "oige_compact_i64_static")
 
 
 def compact(flags: torch.Tensor, workspace: torch.Tensor, ids_out: torch.Tensor, count_out: torch.Tensor) -> None:

@@ -9,6 +9,8 @@
 //   emit  : per wave, rank = group offset + earlier waves + mbcnt(ballot); ids[rank] = env
 // The task kernels (locomotion.hip, cartpole.hip, ...) fuse `count` into their DONE stage and
 // `emit` into their reset stage, so a steady-state step only adds the tiny `scan` launch.
+#include <atomic>
+
 #include "oige_common.hpp"
 #include "oige_scan.hpp"
 #include "oige_tile.hpp"
@@ -88,6 +90,35 @@ int launch_scan_groups2(int64_t n, int32_t* ws_a, int32_t* ws_b, hipStream_t str
   return check_launch("scan_groups2_kernel");
 }
 
+// ---------------------------------------------------------------- the entry point that allocates nothing
+// oige_compact_i64_static: oige_compact_i64 with the reset workspace (tile counts | group offsets | total) in a
+// file-scope device array instead of a caller-provided buffer.  Each GPU the library runs on holds its own copy of the
+// array until the process ends; the array's NAME is only a host-side stand-in, the kernels get the per-device address
+// that hipGetSymbolAddress returned for it.
+constexpr int64_t STATIC_MAX_ENVS = (int64_t)1 << 22;  // 4 M flags per call
+constexpr int64_t STATIC_SCRATCH_INTS = (STATIC_MAX_ENVS / TILE) + (STATIC_MAX_ENVS / GROUP) + 4;  // 81 924 ints = 320 KiB
+static __device__ __align__(256) int32_t scratch[STATIC_SCRATCH_INTS];
+
+constexpr int STATIC_MAX_DEVICES = 64;
+static std::atomic<int32_t*> scratch_ptr[STATIC_MAX_DEVICES];  // per device: each GPU has its own copy at its own address
+
+// The address of `scratch` on the CURRENT device (looked up once per device, with that device current).
+static int static_scratch(int32_t** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= STATIC_MAX_DEVICES)
+    return fail(OIGE_ELAUNCH, "compact_static: no current HIP device (or device index >= %d)", STATIC_MAX_DEVICES);
+  int32_t* p = scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!p) {
+    void* sym = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !sym) return fail(OIGE_ELAUNCH, "compact_static: hipGetSymbolAddress(scratch): %s", hipGetErrorString(e));
+    p = static_cast<int32_t*>(sym);
+    scratch_ptr[dev].store(p, std::memory_order_release);  // two racing first calls look the same address up twice
+  }
+  *out = p;
+  return OIGE_OK;
+}
+
 }  // namespace oige
 
 using namespace oige;
@@ -136,6 +167,22 @@ int oige_compact_i64(const int64_t* flags, int64_t n, int32_t* workspace, int64_
   }
   return hipMemsetAsync(count_out, 0, sizeof(int64_t), s) == hipSuccess ? OIGE_OK
                                                                         : fail(OIGE_ELAUNCH, "compact: memset failed");
+}
+
+int64_t oige_compact_static_max_envs(void) { return STATIC_MAX_ENVS; }
+
+int oige_compact_i64_static(const int64_t* flags, int64_t n, int64_t* ids_out, int64_t* count_out, oige_stream_t stream) {
+  OIGE_REQUIRE(flags && ids_out && count_out, "compact_static: null pointer");
+  OIGE_REQUIRE(n >= 0, "compact_static: num_envs %lld out of range", (long long)n);
+  OIGE_REQUIRE(n <= STATIC_MAX_ENVS, "compact_static: %lld flags exceed the static scratch (at most %lld per call); use "
+               "oige_compact_i64 with a caller workspace", (long long)n, (long long)STATIC_MAX_ENVS);
+  static_assert(STATIC_SCRATCH_INTS >= (STATIC_MAX_ENVS / GROUP) * GROUP_TILES + STATIC_MAX_ENVS / GROUP + 1, "scratch too small");
+  int32_t* ws = nullptr;
+  int rc = static_scratch(&ws);
+  if (rc) return rc;
+  // Nothing in the scratch has to start at zero: count writes every tile count of the n envs' groups (padding tiles
+  // included), scan every group offset and the total, and emit reads only those -- the last call's contents are dead.
+  return oige_compact_i64(flags, n, ws, ids_out, count_out, stream);
 }
 
 }  // extern "C"
