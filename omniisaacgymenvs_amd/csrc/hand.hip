@@ -34,7 +34,10 @@ constexpr int HD = OIGE_HAND_DOFS;        // 24
 constexpr int HA = OIGE_HAND_ACTIONS;     // 20
 constexpr int HF = OIGE_HAND_FINGERTIPS;  // 5
 constexpr int HS = OIGE_HAND_STATES;      // 187
-constexpr int HNT = 256;                  // threads per tile
+#ifndef OIGE_HAND_NT
+#define OIGE_HAND_NT 256
+#endif
+constexpr int HNT = OIGE_HAND_NT;         // threads per tile
 
 struct HandPost {
   oige_hand_params p;
@@ -114,8 +117,14 @@ constexpr int HTE = 32;
 #endif
 constexpr int HPE = OIGE_HAND_TE;  // envs per pass (64 = the whole tile in one pass)
 
-template <bool NEED_FULLCOLS, bool ASYM>
+// in-kernel DR: the pass's slice of the correlated-noise buffer is fetched with the inputs where that costs <= 8 VGPRs
+// (openai obs: 2 float4 per thread); the 157-column obs reads it inside the epilogue loop instead (5 float4 per thread)
+template <int OW>
+constexpr bool hand_prefetch_corr() { return WgChunk<OW, HNT, HPE>::ITERS <= 2; }
+
+template <bool NEED_FULLCOLS, bool ASYM, int OW>
 struct HandLoads {
+  WgChunk<hand_prefetch_corr<OW>() ? OW : 4, HNT, HPE> c_corr;
   WgChunk<HD, HNT, HPE> c_dpos, c_dvel;
   WgChunk<3 * HF, HNT, HPE> c_ftp;
   WgChunk<4 * HF, HNT, HPE> c_ftr;
@@ -135,8 +144,10 @@ struct HandTileAcc {
 // OBS: 0 openai, 2 full.  ASYM: also states_buf.
 template <int OBS, bool ASYM, bool FULL>
 __device__ __forceinline__ void hand_post_load(const HandPost& a, int64_t env0, int nv,
-                                               HandLoads<ASYM || OBS == OIGE_HAND_OBS_FULL, ASYM>& L, const int tid) {
+                                               HandLoads<ASYM || OBS == OIGE_HAND_OBS_FULL, ASYM, OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157>& L,
+                                               const int tid) {
   constexpr bool NEED_FULLCOLS = ASYM || OBS == OIGE_HAND_OBS_FULL;  // dof/ft_rot/ft_vel columns wanted
+  constexpr int OW = OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157;
   const bool do_progress = a.stages & OIGE_STAGE_PROGRESS;
   const bool do_metrics = a.stages & OIGE_STAGE_METRICS;
   if (a.stages & OIGE_STAGE_OBS) {
@@ -149,6 +160,8 @@ __device__ __forceinline__ void hand_post_load(const HandPost& a, int64_t env0, 
       wg_load_chunk<6 * HF, HNT, FULL, HPE>(L.c_ftv, a.s.fingertip_velocities + env0 * 6 * HF, nv * 6 * HF, tid);
     }
     if (ASYM) wg_load_chunk<6 * HF, HNT, FULL, HPE>(L.c_sens, a.s.vec_sensor + env0 * 6 * HF, nv * 6 * HF, tid);
+    if (hand_prefetch_corr<OW>() && a.dr && a.dn.on_reset.enabled)  // inside the epilogue loop it is a second exposed memory latency per pass
+      wg_load_chunk<hand_prefetch_corr<OW>() ? OW : 4, HNT, FULL, HPE>(L.c_corr, a.dn.correlated_noise + env0 * OW, nv * OW, tid);
   }
   // per-env rows (first lanes of wave 0: one env per lane)
   const bool live = tid < HPE && (FULL || tid < nv);
@@ -185,17 +198,19 @@ __device__ __forceinline__ void hand_post_load(const HandPost& a, int64_t env0, 
 
 template <int OBS, bool ASYM, bool FULL>
 __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __restrict__ lds, int64_t env0, int nv,
-                                                  const HandLoads<ASYM || OBS == OIGE_HAND_OBS_FULL, ASYM>& L,
+                                                  const HandLoads<ASYM || OBS == OIGE_HAND_OBS_FULL, ASYM, OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157>& L,
                                                   HandTileAcc& acc, const int tid) {
   constexpr int OW = OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157;
   constexpr bool NEED_FULLCOLS = ASYM || OBS == OIGE_HAND_OBS_FULL;
-  // LDS carve: [obs tile | states tile | env_pos HPEx3 | lo 24 | hi 24 | noise decisions HPE]
+  // LDS carve: [obs tile | states tile | env_pos HPEx3 | lo 24 | hi 24 | noise decisions HPE | reset-env list HPE + count]
   float* obs_t = lds;
   float* st_t = lds + HPE * OW;
   float* s_env = st_t + (ASYM ? HPE * HS : 0);
   float* s_lo = s_env + HPE * 3;
   float* s_hi = s_lo + HD;
   int* s_dec = reinterpret_cast<int*>(s_hi + HD);  // HPE noise decisions (dr only)
+  int* s_rl = s_dec + HPE;                         // envs of this pass that reset (compacted, ascending), then their count
+  constexpr int AC0 = OBS == OIGE_HAND_OBS_OPENAI ? 22 : 137;  // first action column of the obs tile
 
   const oige_hand_params& p = a.p;
   const bool do_progress = a.stages & OIGE_STAGE_PROGRESS;
@@ -212,9 +227,12 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
     s_env[tid * 3 + 1] = epos.y;
     s_env[tid * 3 + 2] = epos.z;
   }
-  if (tid >= TILE && tid < TILE + HD) {
-    s_lo[tid - TILE] = p.dof_lower[tid - TILE];
-    s_hi[tid - TILE] = p.dof_upper[tid - TILE];
+  {
+    const int j = HNT > TILE ? tid - TILE : tid;  // a second wave fills the limit tables where there is one
+    if (j >= 0 && j < HD) {
+      s_lo[j] = p.dof_lower[j];
+      s_hi[j] = p.dof_upper[j];
+    }
   }
   __syncthreads();
 
@@ -263,6 +281,8 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
 
   // ---- C: per-env math (wave 0)
   float action_penalty = 0.f;
+  const bool tile_actions = (a.stages & OIGE_STAGE_OBS) && do_metrics;  // the action columns are in the tile: no 2nd HBM pass
+  if (tile_actions) __syncthreads();
   if (tid < WAVE) {
     const f3 opl{opos.x - epos.x, opos.y - epos.y, opos.z - epos.z};  // object_pos -= env_pos (:258)
     if ((a.stages & OIGE_STAGE_OBS) && envlane) {
@@ -291,7 +311,16 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
       // torch.sum(actions**2, dim=-1) (:493); the tile row is read straight from global here because
       // with OBS skipped the tile holds no actions
       const float4* ar = reinterpret_cast<const float4*>(a.b.actions + env * HA);
-      if (live) {
+      if (tile_actions) {
+        if (envlane) {
+          const float* at = obs_t + tid * OW + AC0;  // same values, same summation order as the global walk below
+#pragma unroll
+          for (int k = 0; k < HA; ++k) {
+            const float sq = at[k] * at[k];
+            action_penalty = k == 0 ? sq : action_penalty + sq;
+          }
+        }
+      } else if (live) {
 #pragma unroll
         for (int k = 0; k < HA / 4; ++k) {
           const float4 v = ar[k];
@@ -311,10 +340,18 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
         a.b.successes[env] = o.successes;
         if (a.b.randomization_buf) a.b.randomization_buf[env] += 1;  // :297
       }
-      if (a.dr && envlane) {  // the wrapper hands the noise the reset_buf this step just produced (vec_env_rlgames.py:94-97)
-        const NoiseDecision d = noise_decide_flag(a.dn, env, live, live && o.resets != 0);
-        if (live) a.dn.counter[env] = d.cnt;
-        s_dec[tid] = (d.reset ? 1 : 0) | (d.interval ? 2 : 0);
+      if (a.dr) {  // the wrapper hands the noise the reset_buf this step just produced (vec_env_rlgames.py:94-97)
+        NoiseDecision d{false, false, 0};
+        if (envlane) {
+          d = noise_decide_flag(a.dn, env, live, live && o.resets != 0);
+          if (live) a.dn.counter[env] = d.cnt;
+          s_dec[tid] = (d.reset ? 1 : 0) | (d.interval ? 2 : 0);
+        }
+        // the pass's reset envs, compacted: their correlated noise is refreshed on dense lanes below
+        const bool rs = envlane && d.reset && a.dn.on_reset.enabled;
+        const unsigned long long mrs = __ballot(rs);
+        if (rs) s_rl[rank_below(mrs)] = tid;
+        if (tid == 0) s_rl[HPE] = __popcll(mrs);
       }
       const bool r1 = live && o.resets != 0, g1 = live && o.goal_resets != 0;
       const unsigned long long mr = __ballot(r1), mg = __ballot(g1);
@@ -337,15 +374,51 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
       const int64_t base = env0 * OW;  // a multiple of 4: env0 is a multiple of HPE and HPE * OW % 4 == 0
       const int total = nv * OW;
       const bool has_reset = a.dn.on_reset.enabled != 0;
-#pragma unroll 1
-      for (int f = tid; f < NF4; f += HNT) {
+      // D0: correlated_noise[reset_ids] = sample (randomize.py:379-400) on the COMPACTED reset rows: work item = (reset
+      // env, one of the float4 groups its row touches), dense over the workgroup's lanes.  The fresh value goes to the
+      // buffer in HBM and is folded into the obs tile here; D1 then skips the stored value for those elements.
+      const int n_rs = has_reset ? s_rl[HPE] : 0;  // uniform over the workgroup (dr implies the METRICS stage)
+      if (n_rs > 0) {
+        constexpr int GPR = (OW + 3 + 3) / 4;  // float4 groups of the flat (N,OW) buffer one row can touch
+        const bool scale_r = a.dn.on_reset.operation == OIGE_NOISE_SCALING;
+        for (int it = tid; it < n_rs * GPR; it += HNT) {
+          const int r = it / GPR, j = it - r * GPR;
+          const int le = s_rl[r];
+          const int64_t row0 = base + (int64_t)le * OW;  // flat index of the row's first element
+          const int64_t gf = (row0 >> 2) + j;
+          const int64_t el0 = gf << 2;
+          if (el0 < row0 + OW) {
+            float sr[4];
+            noise_reset_samples(a.dn, gf, sr);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int col = (int)(el0 + k - row0);
+              if (col >= 0 && col < OW) {
+                a.dn.correlated_noise[el0 + k] = sr[k];
+                float* o = obs_t + le * OW + col;
+                *o = scale_r ? *o * sr[k] : *o + sr[k];
+              }
+            }
+          }
+        }
+        __syncthreads();
+      }
+      constexpr int CIT = WgChunk<OW, HNT, HPE>::ITERS;
+#pragma unroll
+      for (int ci = 0; ci < CIT; ++ci) {
+        const int f = ci * HNT + tid;
+        if (f >= NF4) continue;
         const int e = 4 * f;
-        if (!FULL && e >= total) break;
+        if (!FULL && e >= total) continue;
         const int nvalid = FULL ? 4 : (total - e < 4 ? total - e : 4);
         const float4 t4 = *reinterpret_cast<const float4*>(obs_t + e);
-        float v[4] = {t4.x, t4.y, t4.z, t4.w}, c[4] = {0.f, 0.f, 0.f, 0.f};
-        float* cor = a.dn.correlated_noise + base + e;
-        if (has_reset) {
+        float v[4] = {t4.x, t4.y, t4.z, t4.w};
+        float c[4] = {0.f, 0.f, 0.f, 0.f};
+        if (hand_prefetch_corr<OW>()) {
+          const float4 q = L.c_corr.v[hand_prefetch_corr<OW>() ? ci : 0];
+          c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w;
+        } else if (has_reset) {
+          const float* cor = a.dn.correlated_noise + base + e;
           if (nvalid == 4) {
             const float4 q = LD4S(cor);
             c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w;
@@ -359,19 +432,17 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
           dec[k] = s_dec[le < HPE ? le : HPE - 1];
           if (++col == OW) { col = 0; ++le; }
         }
-        const bool dirty = noise_apply4(a.dn, dec, nvalid, (base + e) >> 2, v, c);
+        noise_apply4_refreshed(a.dn, dec, nvalid, (base + e) >> 2, v, c);
         float* ob = a.b.obs_buf + base + e;
         float* cl = a.dn.clamped_out ? a.dn.clamped_out + base + e : nullptr;
         if (nvalid == 4) {
           ST4S(ob, make_float4(v[0], v[1], v[2], v[3]));
-          if (dirty) *reinterpret_cast<float4*>(cor) = make_float4(c[0], c[1], c[2], c[3]);
           if (cl)
             ST4S(cl, make_float4(clamp_sym(v[0], a.dn.clip), clamp_sym(v[1], a.dn.clip), clamp_sym(v[2], a.dn.clip),
                                  clamp_sym(v[3], a.dn.clip)));
         } else {
           for (int k = 0; k < nvalid; ++k) {
             ob[k] = v[k];
-            if (dirty) cor[k] = c[k];
             if (cl) cl[k] = clamp_sym(v[k], a.dn.clip);
           }
         }
@@ -397,7 +468,7 @@ __device__ __forceinline__ void hand_post_tile(const HandPost& a, float* __restr
       // two-pass scheme is for
       int tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
-      HandLoads<ASYM || OBS == OIGE_HAND_OBS_FULL, ASYM> L;
+      HandLoads<ASYM || OBS == OIGE_HAND_OBS_FULL, ASYM, OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157> L;
       hand_post_load<OBS, ASYM, FULL>(a, t * TILE + h * HPE, nv, L, tid);
       hand_post_process<OBS, ASYM, FULL>(a, lds, t * TILE + h * HPE, nv, L, acc, tid);
     }
@@ -994,7 +1065,7 @@ static int check_hand(const oige_hand_params* p, const oige_hand_buffers* b, int
 template <int OBS, bool ASYM>
 static int launch_hand_post(const HandPost& a, hipStream_t s) {
   constexpr int OW = OBS == OIGE_HAND_OBS_OPENAI ? 42 : 157;
-  const size_t lds = sizeof(float) * (HPE * OW + (ASYM ? HPE * HS : 0) + HPE * 3 + 2 * HD + HPE);
+  const size_t lds = sizeof(float) * (HPE * OW + (ASYM ? HPE * HS : 0) + HPE * 3 + 2 * HD + HPE + HPE + 4);
   static bool configured = false;
   if (!configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hand_post_kernel<OBS, ASYM>),

@@ -94,6 +94,38 @@ __device__ __forceinline__ bool noise_apply4(const oige_noise_args& a, const int
   return dirty;
 }
 
+// The two halves of noise_apply4 for kernels that refresh the correlated noise of reset envs on COMPACTED rows first
+// (a wave no longer runs the second Philox + Box-Muller because one of its lanes holds a reset env):
+// noise_reset_samples = the four fresh correlated-noise samples of flat float4 `gf` (same key as noise_apply4);
+// noise_apply4_refreshed = noise_apply4 for a quad whose reset elements (dec & 1) already carry their fresh sample in v.
+__device__ __forceinline__ void noise_reset_samples(const oige_noise_args& a, int64_t gf, float (&sr)[4]) {
+  const uint64_t step = a.step_ptr ? *a.step_ptr : a.step;
+  const u4 cc{(uint32_t)gf, (uint32_t)(gf >> 32) | ((uint32_t)(4 + 2 * a.stream_id) << 16), (uint32_t)step, (uint32_t)(step >> 32)};
+  noise_samples(a.on_reset, philox4x32_10(cc, (uint32_t)a.seed, (uint32_t)(a.seed >> 32)), sr);
+}
+
+__device__ __forceinline__ void noise_apply4_refreshed(const oige_noise_args& a, const int (&dec)[4], int nvalid, int64_t gf,
+                                                       float (&v)[4], const float (&c)[4]) {
+  const bool has_reset = a.on_reset.enabled != 0;
+  const bool scale_r = a.on_reset.operation == OIGE_NOISE_SCALING, scale_i = a.on_interval.operation == OIGE_NOISE_SCALING;
+  const uint64_t step = a.step_ptr ? *a.step_ptr : a.step;
+  bool have_i = false;
+  float si[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k >= nvalid) continue;
+    if (has_reset && !(dec[k] & 1)) v[k] = scale_r ? v[k] * c[k] : v[k] + c[k];
+    if (dec[k] & 2) {
+      if (!have_i) {
+        const u4 cc{(uint32_t)gf, (uint32_t)(gf >> 32) | ((uint32_t)(5 + 2 * a.stream_id) << 16), (uint32_t)step, (uint32_t)(step >> 32)};
+        noise_samples(a.on_interval, philox4x32_10(cc, (uint32_t)a.seed, (uint32_t)(a.seed >> 32)), si);
+        have_i = true;
+      }
+      v[k] = scale_i ? v[k] * si[k] : v[k] + si[k];
+    }
+  }
+}
+
 // what a fused kernel may be handed: Philox samples only, the buffer and width it expects
 inline int noise_validate_fused(const oige_noise_args* a, const void* buffer, int width, const char* who) {
   OIGE_REQUIRE(a->buffer == buffer && a->width == width, "%s: noise args must address the kernel's own (N,%d) buffer", who, width);

@@ -168,10 +168,18 @@ __device__ __forceinline__ void wg_for_each(const WgChunk<K, NT, TE>& c, F&& fn,
     if (f >= WgChunk<K, NT, TE>::NF4) continue;
     const int e = 4 * f;
     const float tv[4] = {c.v[it].x, c.v[it].y, c.v[it].z, c.v[it].w};
+    // one division per float4, not per element: the scatter address arithmetic was a third of the wide-row kernels'
+    // VALU instructions.  K % 4 == 0: a float4 never straddles two rows.
+    int row = e / K, col = e - row * K;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int ee = e + k;
-      fn(ee / K, ee % K, tv[k]);
+      fn(row, col, tv[k]);
+      if (K % 4 == 0) {
+        ++col;
+      } else if (++col == K) {
+        col = 0;
+        ++row;
+      }
     }
   }
 }
