@@ -64,7 +64,7 @@ __global__ __launch_bounds__(GROUP) void dr_noise_apply_kernel(const oige_noise_
   const bool has_reset = a.on_reset.enabled != 0;
   const bool scale_r = a.on_reset.operation == OIGE_NOISE_SCALING, scale_i = a.on_interval.operation == OIGE_NOISE_SCALING;
   const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
-  const uint64_t step = a.step_ptr ? *a.step_ptr : a.step;  // device counter: graph replay
+  const uint64_t step = step_of(a);  // device counter: graph replay
   const uint32_t s_lo = (uint32_t)step, s_hi = (uint32_t)(step >> 32);
 
   for (int f = lane; 4 * f < total; f += WAVE) {

@@ -132,8 +132,9 @@ struct HandLoads {
   WgChunk<HA, HNT, HPE> c_act;
   f3 epos, opos, olin, oang, gpos;
   q4 orot, grot;
-  int64_t reset_in, reset_goal_in, progress;
+  int64_t reset_in, reset_goal_in, progress, rand_in;
   float successes;
+  int cnt_in;  // in-kernel DR: the env's noise counter
 };
 
 struct HandTileAcc {
@@ -168,8 +169,9 @@ __device__ __forceinline__ void hand_post_load(const HandPost& a, int64_t env0, 
   const int64_t env = env0 + tid;
   L.epos = L.opos = L.olin = L.oang = L.gpos = f3{0, 0, 0};
   L.orot = L.grot = q4{1, 0, 0, 0};
-  L.reset_in = L.reset_goal_in = L.progress = 0;
+  L.reset_in = L.reset_goal_in = L.progress = L.rand_in = 0;
   L.successes = 0.f;
+  L.cnt_in = 0;
   if (live) {
     const float* e3 = a.s.env_pos + env * 3;
     L.epos = f3{e3[0], e3[1], e3[2]};
@@ -192,6 +194,10 @@ __device__ __forceinline__ void hand_post_load(const HandPost& a, int64_t env0, 
       L.reset_in = a.b.reset_buf[env];
       L.reset_goal_in = a.b.reset_goal_buf[env];
       L.successes = a.b.successes[env];
+      // read-modify-write state of the METRICS stage, fetched here with the inputs: loaded after the stage's stores,
+      // each would wait for those stores' round trip to HBM (loads and stores share vmcnt)
+      if (a.b.randomization_buf) L.rand_in = a.b.randomization_buf[env];
+      if (a.dr) L.cnt_in = a.dn.counter[env];
     }
   }
 }
@@ -226,6 +232,18 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
     s_env[tid * 3 + 0] = epos.x;
     s_env[tid * 3 + 1] = epos.y;
     s_env[tid * 3 + 2] = epos.z;
+  }
+  // The correlated-noise quads were fetched before env_pos, so they have arrived by now; pin that here.  Left to their
+  // first use in the epilogue, the compiler waits for them with vmcnt(0) AFTER the previous quad's stores were issued,
+  // i.e. every quad of noise waited for a store round trip to HBM.
+  constexpr int CIT = WgChunk<OW, HNT, HPE>::ITERS;
+  float4 cq[hand_prefetch_corr<OW>() ? CIT : 1];
+  if (hand_prefetch_corr<OW>()) {
+#pragma unroll
+    for (int ci = 0; ci < CIT; ++ci) {
+      cq[ci] = L.c_corr.v[hand_prefetch_corr<OW>() ? ci : 0];
+      asm volatile("" : "+v"(cq[ci].x), "+v"(cq[ci].y), "+v"(cq[ci].z), "+v"(cq[ci].w));
+    }
   }
   {
     const int j = HNT > TILE ? tid - TILE : tid;  // a second wave fills the limit tables where there is one
@@ -338,12 +356,12 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
         a.b.reset_goal_buf[env] = o.goal_resets;
         a.b.progress_buf[env] = o.progress;
         a.b.successes[env] = o.successes;
-        if (a.b.randomization_buf) a.b.randomization_buf[env] += 1;  // :297
+        if (a.b.randomization_buf) a.b.randomization_buf[env] = L.rand_in + 1;  // :297
       }
       if (a.dr) {  // the wrapper hands the noise the reset_buf this step just produced (vec_env_rlgames.py:94-97)
         NoiseDecision d{false, false, 0};
         if (envlane) {
-          d = noise_decide_flag(a.dn, env, live, live && o.resets != 0);
+          d = noise_decide_cnt(a.dn, L.cnt_in, live, live && o.resets != 0);
           if (live) a.dn.counter[env] = d.cnt;
           s_dec[tid] = (d.reset ? 1 : 0) | (d.interval ? 2 : 0);
         }
@@ -403,7 +421,6 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
         }
         __syncthreads();
       }
-      constexpr int CIT = WgChunk<OW, HNT, HPE>::ITERS;
 #pragma unroll
       for (int ci = 0; ci < CIT; ++ci) {
         const int f = ci * HNT + tid;
@@ -415,7 +432,7 @@ __device__ __forceinline__ void hand_post_process(const HandPost& a, float* __re
         float v[4] = {t4.x, t4.y, t4.z, t4.w};
         float c[4] = {0.f, 0.f, 0.f, 0.f};
         if (hand_prefetch_corr<OW>()) {
-          const float4 q = L.c_corr.v[hand_prefetch_corr<OW>() ? ci : 0];
+          const float4 q = cq[hand_prefetch_corr<OW>() ? ci : 0];
           c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w;
         } else if (has_reset) {
           const float* cor = a.dn.correlated_noise + base + e;
@@ -482,11 +499,12 @@ __device__ __forceinline__ void hand_post_tile(const HandPost& a, float* __restr
   }
 }
 
-#ifdef OIGE_HAND_WAVES_PER_EU
-#define OIGE_HAND_OCC __attribute__((amdgpu_waves_per_eu(OIGE_HAND_WAVES_PER_EU)))
-#else
-#define OIGE_HAND_OCC
+// four waves per SIMD = four workgroups per CU: the register allocator otherwise drifts a few registers past 128 and
+// loses a workgroup per CU (no spills at 128; at 96, for a fifth workgroup, it spills 100+)
+#ifndef OIGE_HAND_WAVES_PER_EU
+#define OIGE_HAND_WAVES_PER_EU 4
 #endif
+#define OIGE_HAND_OCC __attribute__((amdgpu_waves_per_eu(OIGE_HAND_WAVES_PER_EU)))
 template <int OBS, bool ASYM>
 __global__ __launch_bounds__(HNT) OIGE_HAND_OCC void hand_post_kernel(const HandPost a) {
   extern __shared__ __align__(16) float lds[];

@@ -310,7 +310,7 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
       u[D + j] = r.u_vel[k * D + j];
     }
   } else {
-    const uint64_t step = r.step_ptr ? *r.step_ptr : r.step;  // device counter: graph replay (include/oige_hip.h)
+    const uint64_t step = step_of(r);  // device counter: graph replay (include/oige_hip.h)
 #pragma unroll
     for (int blk = 0; blk < (2 * D + 3) / 4; ++blk) {
       const u4 c{(uint32_t)i, (uint32_t)blk, (uint32_t)step, (uint32_t)(step >> 32)};

@@ -164,10 +164,18 @@ OIGE_DEV u4 philox4x32_10(u4 c, uint32_t k0, uint32_t k1) {
   }
   return c;
 }
+// A uniform, launch-invariant 64-bit device scalar (a step counter a graph node advanced BEFORE this kernel), read through
+// the constant address space: the compiler may then use a scalar load, hoist it and read it once.  As a plain global load
+// every use was a conditional vector load followed by `s_waitcnt vmcnt(0)` at the join -- which also waits for every
+// store the wave has in flight: in the ShadowHand noise epilogue each float4 of noise waited for the previous float4's
+// stores to reach HBM, whether or not the pointer was set.
+typedef const uint64_t __attribute__((address_space(4))) * oige_const_u64_ptr;
+OIGE_DEV uint64_t load_uniform_u64(const uint64_t* p) { return *(oige_const_u64_ptr)(uintptr_t)p; }
+
 // top 24 bits -> [0,1) exactly representable in fp32 (same grid torch.rand draws from)
 // the Philox step counter of a reset_io block: by value, or from the device scalar a replayed HIP graph advances
 template <class R>
-OIGE_DEV uint64_t step_of(const R& r) { return r.step_ptr ? *r.step_ptr : r.step; }
+OIGE_DEV uint64_t step_of(const R& r) { return r.step_ptr ? load_uniform_u64(r.step_ptr) : r.step; }
 
 OIGE_DEV float u01(const uint32_t x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
 

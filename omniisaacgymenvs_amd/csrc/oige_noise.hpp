@@ -15,6 +15,20 @@ struct NoiseDecision {
 
 // counter logic of :284-286 and :299-304 for one env
 // (`reset` given by the caller: the fused kernels hold the flag in a register)
+// `cnt` = counter[env] as the caller fetched it (kernels that store before they get here fetch it with their inputs: a
+// load issued after a store waits, through vmcnt, for that store's round trip to HBM)
+__device__ __forceinline__ NoiseDecision noise_decide_cnt(const oige_noise_args& a, int cnt, bool live, bool reset) {
+  NoiseDecision d{false, false, 0};
+  if (!live) return d;
+  d.reset = reset;
+  if (d.reset) cnt = 0;
+  cnt += 1;
+  d.interval = a.on_interval.enabled && cnt >= a.on_interval.frequency_interval;
+  if (d.interval) cnt = 0;
+  d.cnt = cnt;
+  return d;
+}
+
 __device__ __forceinline__ NoiseDecision noise_decide_flag(const oige_noise_args& a, int64_t env, bool live, bool reset) {
   NoiseDecision d{false, false, 0};
   if (!live) return d;
@@ -63,7 +77,7 @@ __device__ __forceinline__ bool noise_apply4(const oige_noise_args& a, const int
   const bool has_reset = a.on_reset.enabled != 0;
   const bool scale_r = a.on_reset.operation == OIGE_NOISE_SCALING, scale_i = a.on_interval.operation == OIGE_NOISE_SCALING;
   const uint32_t k0 = (uint32_t)a.seed, k1 = (uint32_t)(a.seed >> 32);
-  const uint64_t step = a.step_ptr ? *a.step_ptr : a.step;  // device counter: graph replay
+  const uint64_t step = step_of(a);  // device counter: graph replay
   const uint32_t s_lo = (uint32_t)step, s_hi = (uint32_t)(step >> 32);
   bool have_r = false, have_i = false, dirty = false;
   float sr[4], si[4];
@@ -99,7 +113,7 @@ __device__ __forceinline__ bool noise_apply4(const oige_noise_args& a, const int
 // noise_reset_samples = the four fresh correlated-noise samples of flat float4 `gf` (same key as noise_apply4);
 // noise_apply4_refreshed = noise_apply4 for a quad whose reset elements (dec & 1) already carry their fresh sample in v.
 __device__ __forceinline__ void noise_reset_samples(const oige_noise_args& a, int64_t gf, float (&sr)[4]) {
-  const uint64_t step = a.step_ptr ? *a.step_ptr : a.step;
+  const uint64_t step = step_of(a);
   const u4 cc{(uint32_t)gf, (uint32_t)(gf >> 32) | ((uint32_t)(4 + 2 * a.stream_id) << 16), (uint32_t)step, (uint32_t)(step >> 32)};
   noise_samples(a.on_reset, philox4x32_10(cc, (uint32_t)a.seed, (uint32_t)(a.seed >> 32)), sr);
 }
@@ -108,7 +122,7 @@ __device__ __forceinline__ void noise_apply4_refreshed(const oige_noise_args& a,
                                                        float (&v)[4], const float (&c)[4]) {
   const bool has_reset = a.on_reset.enabled != 0;
   const bool scale_r = a.on_reset.operation == OIGE_NOISE_SCALING, scale_i = a.on_interval.operation == OIGE_NOISE_SCALING;
-  const uint64_t step = a.step_ptr ? *a.step_ptr : a.step;
+  const uint64_t step = step_of(a);
   bool have_i = false;
   float si[4];
 #pragma unroll
