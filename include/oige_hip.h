@@ -171,6 +171,13 @@ typedef struct oige_locomotion_reset_io {
 #define OIGE_PRE_CLAMP_ACTIONS 1u /* fold VecEnvRLGames' torch.clamp(actions, +-clip) (vec_env_rlgames.py:77) */
 #define OIGE_PRE_COUNTS_VALID 2u  /* reset_workspace tile counts already match reset_buf (skip recount) */
 
+/* get_dof_at_limit_cost() as the reference's public method returns it (tasks/ant.py:102-109: jit sum(obs[:, 12:12+D] > 0.99)
+ * -> (N,) int64; tasks/humanoid.py:130-141: scaled, motor-effort-weighted excess over 0.98 -> (N,) fp32), from obs_buf.
+ * cost_out: int64[N] when params->limit_cost_kind == 0, float[N] when 1.  (Inside oige_locomotion_post_physics the METRICS
+ * stage evaluates the same function in registers; this entry point exists for callers of the method itself.)            */
+int oige_locomotion_dof_at_limit_cost(const oige_locomotion_params* params, const float* obs_buf, void* cost_out,
+                                      int64_t num_envs, oige_stream_t stream);
+
 /* LocomotionTask.pre_physics_step (locomotion.py:117-131): compaction of reset_buf, reset_idx of
  * the flagged envs, actions clone, forces = actions * joint_gears * power_scale.
  * actions_out may be NULL (no clone) or alias actions_in.                                   */

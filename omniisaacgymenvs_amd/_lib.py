@@ -351,6 +351,7 @@ SIGNATURES = {
     "oige_compact_i64_static": (C.c_int, [_P, C.c_int64, _P, _P, _P]),
     "oige_locomotion_post_physics": (C.c_int, [C.POINTER(LocomotionParams), C.POINTER(LocomotionState),
                                                C.POINTER(LocomotionBuffers), C.c_int64, C.c_uint32, _P]),
+    "oige_locomotion_dof_at_limit_cost": (C.c_int, [C.POINTER(LocomotionParams), _P, _P, C.c_int64, _P]),
     "oige_locomotion_pre_physics": (C.c_int, [C.POINTER(LocomotionParams), _P, C.POINTER(LocomotionBuffers),
                                               C.POINTER(LocomotionResetIO), _P, _P, C.c_int64, C.c_uint32, _P]),
     "oige_locomotion_reset_idx": (C.c_int, [C.POINTER(LocomotionParams), C.POINTER(LocomotionBuffers),

@@ -516,6 +516,15 @@ constexpr int ANG = 4;
 // per-env scan table (floats): AB[iy] = (w tx, z tx) for the 10 grid columns, CD[ix] = (z ty, w ty) for the 14 grid
 // rows, then (base x, base y, base z - 0.5, -).  13 float4 per env (odd): conflict-free 16-byte rows.
 constexpr int AER = 52, AE_CD = 20, AE_POS = 48;
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+// div_by_const on both halves of a float2 (the same five IEEE operations per half)
+__device__ __forceinline__ v2f div_by_const2(v2f x, float h, float inv) {
+  const v2f hh = {h, h}, ii = {inv, inv};
+  const v2f q0 = x * ii;
+  const v2f q1 = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, hh, x), ii, q0);
+  return __builtin_elementwise_fma(__builtin_elementwise_fma(-q1, hh, x), ii, q1);
+}
 
 __device__ __forceinline__ void cursor_advance(int& e, int& k, int de, int dk, int period) {
   e += de;
@@ -565,6 +574,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
   const int hs_cols = p.hs_cols, max_r = p.hs_rows - 2, max_c = p.hs_cols - 2;
   const float hscale = p.horizontal_scale, hinv = 1.0f / p.horizontal_scale;
   const float nscale = p.noise_scales[5];
+  const v2f border = {p.border_size, p.border_size};
   const int wave = tid >> 6, lane = tid & (WAVE - 1);
   constexpr int NW = ANT / WAVE;
   float* strip = s_strip + wave * 256;
@@ -584,16 +594,16 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
       const float2 ab = *reinterpret_cast<const float2*>(eb + __float_as_int(kk.z));
       const float2 cd = *reinterpret_cast<const float2*>(eb + __float_as_int(kk.w));
       const float4 pp = *reinterpret_cast<const float4*>(eb + 4 * AE_POS);  // base x, y, z - 0.5
-      const float rx = (kk.x + ab.x) + (-cd.x);
-      const float ry = (kk.y + cd.y) + ab.y;
-      const float wx = div_by_const((rx + pp.x) + p.border_size, hscale, hinv);  // :586-593
-      const float wy = div_by_const((ry + pp.y) + p.border_size, hscale, hinv);
+      // both components per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operation on each half)
+      const v2f hxy = {kk.x, kk.y}, t1 = {ab.x, cd.y}, t2 = {-cd.x, ab.y}, bxy = {pp.x, pp.y};
+      const v2f rxy = (hxy + t1) + t2;  // rx = (hx + w tx) + (-(z ty)), ry = (hy + w ty) + (z tx)
+      const v2f w = div_by_const2((rxy + bxy) + border, hscale, hinv);  // :586-593
       // .long() truncates toward zero; v_cvt_i32_f32 does too and saturates, and the clip that follows (:596-597) maps
       // every saturated value where int64 truncation + clip would (out-of-range low -> 0, high -> rows - 2)
-      int px = (int)wx, py = (int)wy;
+      int px = (int)w.x, py = (int)w.y;
       px = max(min(px, max_r), 0);
       py = max(min(py, max_c), 0);
-      idx[g] = px * hs_cols + py;
+      idx[g] = __mul24(px, hs_cols) + py;  // both below 2^24: v_mad_i32_i24 is full rate, v_mul_lo_u32 quarter rate
       pz[g] = pp.z;
       // next pass: +64 points; after the last pass, the first pass of the wave's next chunk: +4*256 - 192 = 5*140 + 132
       if (g != ANG - 1) cursor_advance(pe, pk, 0, 64, AP);

@@ -264,6 +264,23 @@ __global__ __launch_bounds__(256) void locomotion_metrics_kernel(const LocoPost 
                                          a.b.prev_potentials[env]);
 }
 
+// get_dof_at_limit_cost() as a tensor of its own (ant.py:102-109 -> (N,) int64 count, humanoid.py:130-141 -> (N,) fp32):
+// the METRICS stage evaluates the same functions in registers; callers of the public method get them from obs_buf.
+template <int D, int S, int LIMIT>
+__global__ __launch_bounds__(256) void locomotion_limit_cost_kernel(const oige_locomotion_params p, const float* __restrict__ obs_buf,
+                                                                    void* __restrict__ out, int64_t n) {
+  constexpr int OBS = 12 + 3 * D + 6 * S;
+  const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= n) return;
+  float dps[D];
+#pragma unroll
+  for (int j = 0; j < D; ++j) dps[j] = obs_buf[env * OBS + 12 + j];
+  if (LIMIT == 0)
+    static_cast<int64_t*>(out)[env] = (int64_t)limit_cost_ant<D>(dps);  // an exact small integer in fp32
+  else
+    static_cast<float*>(out)[env] = limit_cost_humanoid<D>(dps, p);
+}
+
 __global__ __launch_bounds__(256) void locomotion_done_kernel(const LocoPost a, int obs_width) {
   const int64_t env = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = env < a.n;
@@ -567,6 +584,30 @@ int oige_locomotion_post_physics(const oige_locomotion_params* params, const oig
   }
   hipStream_t s = (hipStream_t)stream;
   return params->num_dof == 8 ? launch_post<8, 4>(a, s) : launch_post<21, 2>(a, s);
+}
+
+int oige_locomotion_dof_at_limit_cost(const oige_locomotion_params* params, const float* obs_buf, void* cost_out,
+                                      int64_t num_envs, oige_stream_t stream) {
+  if (int rc = check_params(params)) return rc;
+  OIGE_REQUIRE(obs_buf && cost_out, "locomotion_dof_at_limit_cost: null pointer");
+  OIGE_REQUIRE(num_envs >= 0 && num_envs < ((int64_t)1 << 31) / 128, "locomotion_dof_at_limit_cost: num_envs %lld out of range",
+               (long long)num_envs);
+  OIGE_REQUIRE((reinterpret_cast<uintptr_t>(cost_out) & 7u) == 0, "locomotion_dof_at_limit_cost: cost_out must be 8-byte aligned");
+  if (num_envs == 0) return OIGE_OK;
+  const unsigned blocks = (unsigned)((num_envs + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (params->num_dof == 8) {
+    if (params->limit_cost_kind == 0)
+      hipLaunchKernelGGL((locomotion_limit_cost_kernel<8, 4, 0>), dim3(blocks), dim3(256), 0, s, *params, obs_buf, cost_out, num_envs);
+    else
+      hipLaunchKernelGGL((locomotion_limit_cost_kernel<8, 4, 1>), dim3(blocks), dim3(256), 0, s, *params, obs_buf, cost_out, num_envs);
+  } else {
+    if (params->limit_cost_kind == 0)
+      hipLaunchKernelGGL((locomotion_limit_cost_kernel<21, 2, 0>), dim3(blocks), dim3(256), 0, s, *params, obs_buf, cost_out, num_envs);
+    else
+      hipLaunchKernelGGL((locomotion_limit_cost_kernel<21, 2, 1>), dim3(blocks), dim3(256), 0, s, *params, obs_buf, cost_out, num_envs);
+  }
+  return check_launch("locomotion_limit_cost_kernel");
 }
 
 int oige_locomotion_pre_physics(const oige_locomotion_params* params, const float* actions_in,

@@ -65,7 +65,5 @@ class AntLocomotionTask(LocomotionTask):
         LocomotionTask.post_reset(self)
 
     def get_dof_at_limit_cost(self):
-        raise NotImplementedError(
-            "the Ant limit cost is evaluated inside oige_locomotion_post_physics (OIGE_STAGE_METRICS); "
-            "there is no standalone tensor version on the product path"
-        )
+        """(N,) int64: per env, how many scaled DOF positions exceed 0.99 -- no abs (ant.py:102-109)."""
+        return self._limit_cost(torch.int64)

@@ -80,6 +80,5 @@ class HumanoidLocomotionTask(LocomotionTask):
         LocomotionTask.post_reset(self)
 
     def get_dof_at_limit_cost(self):
-        raise NotImplementedError(
-            "the Humanoid limit cost is evaluated inside oige_locomotion_post_physics (OIGE_STAGE_METRICS)"
-        )
+        """(N,) fp32: scaled excess over 0.98 of |scaled DOF position|, weighted by motor effort (humanoid.py:130-141)."""
+        return self._limit_cost(torch.float32)

@@ -181,6 +181,17 @@ class LocomotionTask(RLTask):
     def is_done(self) -> None:
         self._post(_lib.STAGE_DONE)
 
+    def _limit_cost(self, dtype) -> torch.Tensor:
+        """``get_dof_at_limit_cost()`` of the subclass (ant.py:102-109 / humanoid.py:130-141) from ``obs_buf``: a fresh
+        ``(N,)`` tensor of the reference's dtype (int64 count for Ant, fp32 for Humanoid)."""
+        out = torch.empty(self._num_envs, dtype=dtype, device=self.obs_buf.device)
+        _lib.require_device_tensor(self.obs_buf, torch.float32, (self._num_envs, self._num_observations), "obs_buf")
+        p = self._params()
+        _lib.check(_lib.load().oige_locomotion_dof_at_limit_cost(C.byref(p), self.obs_buf.data_ptr(), out.data_ptr(), self._num_envs,
+                                                                 _lib.current_stream(self.obs_buf.device)),
+                   "oige_locomotion_dof_at_limit_cost")
+        return out
+
     def post_physics_step(self):
         if not self.fused:
             return RLTask.post_physics_step(self)

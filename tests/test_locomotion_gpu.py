@@ -208,3 +208,28 @@ def test_full_size_properties(name, n):
     obs_o, pot_o, _, _, _ = lo.observations(spec, st["pos"][sl], st["rot"][sl], st["vel"][sl], st["dof_pos"][sl],
                                             st["dof_vel"][sl], st["sensors"][sl], st["actions"][sl], st["potentials"][sl])
     assert_close(obs1[sl], obs_o, "obs slice")
+
+
+@pytest.mark.parametrize("name", ["Ant", "Humanoid"])
+@pytest.mark.parametrize("n", [1, 257, 4096])
+def test_get_dof_at_limit_cost_matches_the_reference_method(name, n):
+    """The public method (ant.py:102-109 -> int64 count, no abs; humanoid.py:130-141 -> fp32) on an obs_buf with the
+    threshold rows SURVEY.md 8c asks for: +-0.98, +-0.99, -0.995, one ULP either side."""
+    env, task, st = _loaded_task(name, n)
+    task.post_physics_step()
+    d = task._robots.num_dof
+    edge = torch.tensor([0.98, -0.98, 0.99, -0.99, -0.995, 0.995, float(np.nextafter(np.float32(0.99), np.float32(2))),
+                         float(np.nextafter(np.float32(0.99), np.float32(0))), float(np.nextafter(np.float32(0.98), np.float32(2))),
+                         float(np.nextafter(np.float32(0.98), np.float32(0))), 1.5, -1.5, 0.0])
+    rows = min(n, len(edge))
+    task.obs_buf[:rows, 12:12 + d] = edge[:rows, None].to(task.obs_buf.device)
+    got = task.get_dof_at_limit_cost()
+    torch.cuda.synchronize()
+    want = lo.dof_at_limit_cost(oracle_spec(task), task.obs_buf.cpu())
+    assert got.shape == (n,) and got.dtype == want.dtype == (torch.int64 if name == "Ant" else torch.float32)
+    if name == "Ant":
+        assert_equal(got, want, "dof_at_limit_cost")  # a count: bit-exact
+        if n >= 6:
+            assert got[:6].tolist() == [0, 0, 0, 0, 0, d]  # no abs: -0.995 does not count
+    else:
+        assert_close(got, want, "dof_at_limit_cost")
