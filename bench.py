@@ -46,8 +46,14 @@ ANYMAL_POST_BYTES = 512 + 560 + 913     # state + 280 int16 gathers + obs/flags/
 
 
 # ---------------------------------------------------------------------------- per-task adapters
+def _pick(n, frac, dev, seed):
+    """Bernoulli(frac) mask over the envs (the envs that terminate on every step of a --reset-frac workload)."""
+    g = torch.Generator(device=dev).manual_seed(seed + 77)
+    return torch.rand(n, device=dev, generator=g) < frac
+
+
 class LocomotionBench:
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -57,11 +63,19 @@ class LocomotionBench:
         self.d, self.s = t._robots.num_dof, t._num_sensors
         z = (0.2, 0.9) if name == "Ant" else (0.5, 1.5)
         st = workloads.locomotion_state(n, t.dof_limits_lower, t.dof_limits_upper, self.s, device=dev, seed=seed, z_range=z)
+        if reset_frac is not None:  # only `reset_frac` of the torsos below the termination height (+ the 1/1000 timeouts)
+            low = _pick(n, reset_frac, dev, seed)
+            zz = st["pos"][:, 2]
+            st["pos"][:, 2] = torch.where(low, torch.full_like(zz, t.termination_height - 0.05),
+                                          zz.clamp(min=t.termination_height + 0.02))
         workloads.load_locomotion_state(t, st)
         t._robots.apply_resets = False  # PhysX-side scatter is delegated; the kernels still compute every reset row
         self.actions = st["actions"]
         ab = locomotion_bytes(self.d, self.s, t.materialize_vecs)
         self.post_bytes = ab["post"]
+        # pre_physics_step: R actions + W actions clone + W forces + R reset flag per env; per reset env R initial dof / root
+        # (4D + 28), W dof_pos / dof_vel rows, root pose + velocity rows, id, potentials x2, reset, progress (8D + 92)
+        self.pre_bytes = lambda resets, d=self.d: (12 * d + 8) * n + (12 * d + 120) * resets
         self.kernel = "locomotion_post_kernel"
         self.workload = f"{name} obs({ab['obs']})+reward+reset fused, {n} envs per GPU, synthetic root/DOF state"
         self.extra_cfg = {"num_dof": self.d, "num_sensors": self.s}
@@ -103,7 +117,7 @@ class LocomotionBench:
 class HandBench:
     """C4: ShadowHandOpenAI_FF (openai obs + asymmetric full_state states + goal-rotation reward) with DR noise."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
         from omniisaacgymenvs_amd.utils.config import TASK_DEFAULTS
@@ -113,6 +127,18 @@ class HandBench:
         self.env, self.task = make_task("ShadowHandOpenAI_FF", n, device=dev, seed=seed, domain_randomization=dr)
         t = self.task
         st = workloads.hand_state(n, t._env_pos, t.goal_pos, t.hand_dof_lower_limits, t.hand_dof_upper_limits, device=dev, seed=seed)
+        if reset_frac is not None:  # `reset_frac` of the objects beyond fall_dist, as many at the goal rotation; no stale flags
+            far, hit = _pick(n, reset_frac, dev, seed), _pick(n, reset_frac, dev, seed + 1)
+            off = st["object_pos"] - (t.goal_pos + t._env_pos)
+            off = off * (0.15 / off.norm(dim=-1, keepdim=True).clamp(min=0.15))          # everyone within 0.15 m ...
+            off = torch.where(far.unsqueeze(-1), off * (0.3 / 0.15), off)                  # ... but these, at 0.3 m (fall_dist 0.24)
+            st["object_pos"] = (t.goal_pos + t._env_pos + off).contiguous()
+            q = torch.randn(n, 4, device=dev)
+            q = q / q.norm(dim=-1, keepdim=True)
+            st["object_rot"] = torch.where(hit.unsqueeze(-1), st["goal_rot"], q).contiguous()
+            st["reset"].zero_()
+            st["reset_goal"].zero_()
+            st["successes"].zero_()
         workloads.load_hand_state(t, st)
         for v in (t._hands, t._objects, t._goals):
             v.apply_resets = False
@@ -124,6 +150,11 @@ class HandBench:
         # in-kernel DR: the post kernel also reads the correlated noise (168), updates the counter (8) and writes the
         # clamped copy the policy receives (168) next to the noised obs_buf
         self.post_bytes = HAND_POST_BYTES + (168 + 8 + 168 if self.fused_dr else 0)
+        # pre_physics_step with the action noise inside: R actions 80, W noised actions 80 (the caller's tensor, in place), R
+        # correlated noise 80, counter RW 8, W actions clone 80, R prev_targets 96, W prev / cur targets 192, W targets_out
+        # 96, R reset + reset_goal flags 16; per reset env ~ 53 draws -> object pose / velocity rows 52, goal rows 28 x2,
+        # dof_pos / dof_vel rows 192, id 8, flags 24, W correlated noise 80; per goal reset: goal rows 28 + 28, id 8, flag 8
+        self.pre_bytes = lambda resets: 728 * n + 412 * resets
         self.kernel = "hand_post_kernel"
         self.workload = (f"ShadowHand openai obs(42) + full_state states(187) + goal-rotation reward + reset_target_pose/reset_idx "
                          f"+ obs/action DR noise ({'applied inside the pre/post kernels' if self.fused_dr else 'separate launches'}), "
@@ -199,18 +230,23 @@ class HandBench:
 class AnymalBench:
     """C5 per-GPU shard: AnymalTerrain height-scan obs + 11-term reward + in-step reset."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
         self.env, self.task = make_task("AnymalTerrain", n, device=dev, seed=seed)
         t = self.task
         st = workloads.anymal_state(n, t.terrain_origins, t.default_dof_pos, device=dev, seed=seed)
+        if reset_frac is not None:  # contacts below the 1 N thresholds except for `reset_frac` of the bases
+            fall = _pick(n, reset_frac, dev, seed)
+            st["knee_contact"] = st["knee_contact"].clamp(max=0.5)
+            st["base_contact"] = torch.where(fall.unsqueeze(-1), torch.full_like(st["base_contact"], 2.0), st["base_contact"].clamp(max=0.5))
         workloads.load_anymal_state(t, st)
         t._anymals.apply_resets = False
         t.decimation = 1  # one PD-torque sub-step per env-step (the other three belong to the delegated physics loop)
         self.actions = st["actions"]
         self.post_bytes = ANYMAL_POST_BYTES
+        self.pre_bytes = lambda resets: 192 * n  # PD torques: R actions, dof_pos, dof_vel + W torques (the resets are in-step, post side)
         self.kernel = "anymal_head_kernel + anymal_scan_kernel (+ flags / scan / norm / extras: the whole post_physics_step)"
         self.workload = (f"AnymalTerrain height-scan obs(188) + 11-term reward + in-step reset + obs noise, {n} envs per GPU, "
                          "synthetic state, 1200x2000 int16 heightfield")
@@ -265,7 +301,9 @@ class AnymalBench:
 class AllegroHandBench:
     """AllegroHand, `full` obs(72) + goal-rotation reward + resets (the YAML has no DR section)."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
+        if reset_frac is not None:
+            raise SystemExit("--reset-frac is defined for Ant, Humanoid, ShadowHand and AnymalTerrain")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -317,7 +355,9 @@ class AllegroHandBench:
 class QuadcopterBench:
     """Quadcopter obs(21) + inverse-quadratic reward + non-sticky done, targets / thrust integration."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
+        if reset_frac is not None:
+            raise SystemExit("--reset-frac is defined for Ant, Humanoid, ShadowHand and AnymalTerrain")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -366,7 +406,9 @@ class QuadcopterBench:
 class BallBalanceBench:
     """BallBalance obs(24) + reward + sticky done, position-target integration."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
+        if reset_frac is not None:
+            raise SystemExit("--reset-frac is defined for Ant, Humanoid, ShadowHand and AnymalTerrain")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -416,7 +458,9 @@ class BallBalanceBench:
 class IngenuityBench:
     """Ingenuity obs(13) + reward + done, reset + set_targets compactions, thrust vectors."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
+        if reset_frac is not None:
+            raise SystemExit("--reset-frac is defined for Ant, Humanoid, ShadowHand and AnymalTerrain")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -464,7 +508,9 @@ class IngenuityBench:
 class CrazyflieBench:
     """Crazyflie obs(18) + 4-term reward + 8 episode sums + done; motor filter, two compactions, extras."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
+        if reset_frac is not None:
+            raise SystemExit("--reset-frac is defined for Ant, Humanoid, ShadowHand and AnymalTerrain")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -512,7 +558,9 @@ class CrazyflieBench:
 class FrankaCabinetBench:
     """FrankaCabinet grasp transforms + obs(23) + 8-term reward + sticky done; target integration, resets."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
+        if reset_frac is not None:
+            raise SystemExit("--reset-frac is defined for Ant, Humanoid, ShadowHand and AnymalTerrain")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -570,7 +618,9 @@ class FrankaCabinetBench:
 class NewhandCabinetBench:
     """the fork's five-finger cabinet tasks (10 keypoints, obs(2D+5), reward, sticky done [+ terminate])."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
+        if reset_frac is not None:
+            raise SystemExit("--reset-frac is defined for Ant, Humanoid, ShadowHand and AnymalTerrain")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -626,7 +676,9 @@ class NewhandCabinetBench:
 class AnymalFlatBench:
     """Anymal on flat ground (obs 48, 6-term reward, non-sticky done, position targets)."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
+        if reset_frac is not None:
+            raise SystemExit("--reset-frac is defined for Ant, Humanoid, ShadowHand and AnymalTerrain")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -741,7 +793,7 @@ class DryBench:
     all-reduce and the max-over-ranks timing of the N>1 path can run where there is no GPU (tests/test_bench_launcher_cpu.py).
     Its line is marked ``"data": "dry-run"``: it measures nothing."""
 
-    def __init__(self, name, n, dev, seed):
+    def __init__(self, name, n, dev, seed, reset_frac=None):
         import types
 
         g = torch.Generator().manual_seed(seed)
@@ -843,6 +895,9 @@ def main() -> None:
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --envs per GPU (default); strong: the one-GPU env count split over the ranks")
     ap.add_argument("--cpu-envs", type=int, default=0)
+    ap.add_argument("--reset-frac", type=float, default=None,
+                    help="second workload: only this fraction of the envs terminates per step (0.001 = the reference's steady "
+                         "state, about N/1000 resets per step, SURVEY.md a8); default: the r01 workload, 13-25 %% per step")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="PMC-derived HBM bytes per launch of the dominant kernel (profiles/run_profiles.sh) -> roofline.traffic")
     args = ap.parse_args()
@@ -864,7 +919,7 @@ def main() -> None:
             raise SystemExit(f"--scaling strong: {n} envs do not split into {world} ranks of whole 64-env tiles")
         n //= world
     with contextlib.redirect_stdout(sys.stderr):  # the task constructors print like the reference's; stdout carries ONE JSON line
-        bench = ADAPTERS[args.task](args.task, n, dev, od.rank_seed(1234, rank))
+        bench = ADAPTERS[args.task](args.task, n, dev, od.rank_seed(1234, rank), reset_frac=args.reset_frac)
 
     # HIP events around the post kernel of every timed step.  They are CREATED here: hipEventCreate inside the loop costs
     # ~100 us per step (measured), recording a ready-made one does not.
@@ -991,6 +1046,18 @@ def main() -> None:
                 "measured_copy_gbs": copy_gbs,
                 "frac_of_measured_copy_12_streams": achieved / copy_gbs["streams_12"],
             }
+            if hasattr(bench, "pre_bytes") and pre_ms:  # the other half of the step, and the step as a whole
+                resets = cfg["resets_per_step"]
+                pb = float(bench.pre_bytes(resets))
+                pre_gbs = pb / (pre_ms * 1e-3) / 1e9
+                step_gbs = (pb + bench.post_bytes * n) / (gpu_span_ms * 1e-3) / 1e9
+                out["roofline"]["pre"] = {"what": "everything the step launches before the post kernel (compaction scan, resets, action scaling)",
+                                          "algorithmic_bytes": pb, "ms": pre_ms, "achieved": pre_gbs, "frac": pre_gbs / HBM_PEAK_GBS}
+                out["roofline"]["step"] = {"what": "pre + post algorithmic bytes over gpu_ms_per_step (first launch to last kernel end)",
+                                           "algorithmic_bytes": pb + bench.post_bytes * n, "ms": gpu_span_ms, "achieved": step_gbs,
+                                           "frac": step_gbs / HBM_PEAK_GBS}
+            if args.reset_frac is not None:
+                cfg["reset_frac"] = args.reset_frac
         if not args.no_cpu_baseline and world == 1 and not dry:
             out["cpu_baseline"] = cpu_baseline(args.task, args.cpu_envs or n)
         print(json.dumps(out), flush=True)
