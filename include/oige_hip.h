@@ -426,6 +426,16 @@ typedef struct oige_anymal_reset_io {
   float* dof_vel_out;        /* out (n,12) */
   const uint64_t* step_ptr; /* NULL, or a device scalar read INSTEAD of `step` (HIP-graph replay), as
                                oige_locomotion_reset_io.step_ptr */
+  /* push_robots (:446-450) on the device, so that no step differs from another on the host (HIP-graph capture):
+   * oige_anymal_post_physics, before anything reads the velocities, sets push_velocities[:, 0:2] = U(-1, 1) for every env
+   * when (step + push_offset) % push_interval == 0 -- `step` as above (by value or *step_ptr), push_offset =
+   * common_step_counter - step on the host (:418-420 counts post_physics_step calls) -- and writes *push_count = N on such
+   * a step, 0 otherwise: the (values, count) hand-over for `set_velocities`.  Draws: Philox stream 7, two per env.
+   * push_velocities NULL or push_interval <= 0: no push (the caller does it, the reference's way).               */
+  float* push_velocities;   /* NULL or (N,6): the view's base velocities, updated in place like the reference does */
+  int64_t* push_count;      /* out device scalar (required with push_velocities) */
+  int64_t push_interval;    /* :131-133 int(pushInterval_s / dt + 0.5) */
+  int64_t push_offset;
 } oige_anymal_reset_io;
 
 /* One decimation sub-step of pre_physics_step (:398-403):

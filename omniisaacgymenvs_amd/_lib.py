@@ -154,7 +154,7 @@ class AnymalResetIO(C.Structure):
         ("seed", C.c_uint64), ("step", C.c_uint64),
         ("env_ids", _fp), ("count", _fp), ("base_pos_out", _fp), ("base_quat_out", _fp), ("base_vel_out", _fp),
         ("dof_pos_out", _fp), ("dof_vel_out", _fp),
-    ]) + [("step_ptr", _fp)]
+    ]) + [("step_ptr", _fp), ("push_velocities", _fp), ("push_count", _fp), ("push_interval", C.c_int64), ("push_offset", C.c_int64)]
 
 
 class AnymalFlatParams(C.Structure):

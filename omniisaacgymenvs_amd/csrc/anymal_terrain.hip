@@ -80,6 +80,17 @@ __global__ __launch_bounds__(GROUP) void anymal_flags_kernel(const AnymalPost a)
   const bool live = env < a.n;
   bool reset = false;
   float cmd2 = 0.0f;
+  if (a.mode == 0 && a.r.push_velocities && a.r.push_interval > 0) {  // push_robots (:419-420, :446-450)
+    const uint64_t c = step_of(a.r) + (uint64_t)a.r.push_offset;       // common_step_counter
+    const bool pushing = c % (uint64_t)a.r.push_interval == 0;          // uniform
+    if (pushing && live) {
+      const u4 cc{(uint32_t)env, 7u << 16, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};
+      const u4 x = philox4x32_10(cc, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
+      // torch_rand_float(-1, 1, (N, 2)): (1 - (-1)) * u + (-1), columns 0:2 of the (N,6) velocities
+      *reinterpret_cast<float2*>(a.r.push_velocities + env * 6) = make_float2(2.0f * u01(x.x) + (-1.0f), 2.0f * u01(x.y) + (-1.0f));
+    }
+    if (env == 0) *a.r.push_count = pushing ? a.n : 0;
+  }
   if (live && a.mode == 0) {
     const int64_t progress = a.b.progress_buf[env] + 1;  // :410
     a.b.progress_buf[env] = progress;
@@ -755,6 +766,8 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
                "anymal: null buffer pointer");
   OIGE_REQUIRE(r.env_ids && r.count && r.base_pos_out && r.base_quat_out && r.base_vel_out && r.dof_pos_out && r.dof_vel_out,
                "anymal: null reset output pointer");
+  OIGE_REQUIRE(!r.push_velocities || (r.push_count && (reinterpret_cast<uintptr_t>(r.push_velocities) & 7u) == 0),
+               "anymal: push_velocities needs push_count and 8-byte alignment");
   const bool drawn = r.u_dof_offset != nullptr;
   OIGE_REQUIRE(drawn == (r.u_dof_vel != nullptr) && drawn == (r.u_xy != nullptr) && drawn == (r.u_cmd != nullptr),
                "anymal: pass all four pre-drawn reset tables or none");

@@ -120,6 +120,8 @@ class SyntheticArticulationView:
         return indices[:n].long()
 
     def _scatter(self, buf: Tensor, values: Tensor, indices, count) -> None:
+        if values.data_ptr() == buf.data_ptr() and values.shape == buf.shape:
+            return  # the caller edited the view's own buffer in place (clone=False getter, e.g. push_robots): nothing to move
         if count is not None and self.apply_resets == "device":
             # rows k >= count must not land: point them at row 0's target and give them row 0's value (duplicates then write
             # identical data), or -- when count == 0 -- at a row that is rewritten with its own current value

@@ -52,8 +52,30 @@ class SyntheticAnymalView(SyntheticArticulationView):
 
 
 class AnymalTerrainTask(RLTask):
-    graph_capturable = ("the step has host-side branches that change from step to step (push_robots every push_interval "
-                        "steps, the curriculum read-backs): a captured graph would freeze one of them")
+    # push_robots (:419-420, :446-450) runs inside oige_anymal_post_physics: the step counter test and the U(-1,1) draws
+    # (Philox stream 7) are on the device, ``set_velocities`` gets (values, indices, count) with a device count that is N on
+    # a push step and 0 otherwise -- no step differs from another on the host, so the step can be captured into a HIP
+    # graph.  ``device_push = False`` restores the reference's host branch with torch's draw (and refuses capture).
+    device_push = True
+    _common_offset = 0
+    sync_free = True   # the in-step reset has always been device-side (count on the device)
+    fused = True
+
+    @property
+    def common_step_counter(self) -> int:
+        """:273, :418: post_physics_step calls so far.  Kept as ``_step_count + offset`` so that replayed graph steps
+        (``replay_step`` advances ``_step_count``) count too and the kernel's ``push_offset`` stays a constant."""
+        return self._step_count + self._common_offset
+
+    @common_step_counter.setter
+    def common_step_counter(self, value: int) -> None:
+        self._common_offset = int(value) - self._step_count
+
+    @property
+    def graph_capturable(self):
+        return True if self.device_push else ("device_push is off: push_robots is a host-side branch that differs from "
+                                               "step to step, a captured graph would freeze one side of it")
+
     def __init__(self, name, sim_config, env, offset=None) -> None:
         self.height_samples = None
         self.custom_origins = False
@@ -208,6 +230,8 @@ class AnymalTerrainTask(RLTask):
         self._reduce_workspace = torch.zeros((16 + 512) * tiles + 4, **f)  # partial sums + pose records (oige_hip.h)
         self._extras_dev = torch.zeros(len(EPISODE_KEYS) + 1, **f)
         i64 = dict(dtype=torch.int64, device=dev)
+        self._push_count = torch.zeros(1, **i64)
+        self._all_indices = torch.arange(n, **i64)
         self._reset_out = {
             "env_ids": torch.zeros(n, **i64), "count": torch.zeros(1, **i64),
             "base_pos": torch.zeros((n, 3), **f), "base_quat": torch.zeros((n, 4), **f), "base_vel": torch.zeros((n, 6), **f),
@@ -298,7 +322,7 @@ class AnymalTerrainTask(RLTask):
         b.reset_workspace, b.reduce_workspace = self._reset_workspace.data_ptr(), self._reduce_workspace.data_ptr()
         return b
 
-    def _reset_io(self, draws=None, noise_u=None, mask=None) -> _lib.AnymalResetIO:
+    def _reset_io(self, draws=None, noise_u=None, mask=None, push=False) -> _lib.AnymalResetIO:
         r = _lib.AnymalResetIO()
         if draws is not None:
             self._live_draws = draws
@@ -310,6 +334,12 @@ class AnymalTerrainTask(RLTask):
             r.reset_mask = mask.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
         r.step = self._step_count
+        r.step_ptr = self._graph_step_ptr()  # graph capture: the step counter lives on the device
+        if push and self.device_push and self.push_interval > 0:
+            _lib.require_device_tensor(self.base_velocities, torch.float32, (self._num_envs, 6), "base_velocities")
+            r.push_velocities, r.push_count = self.base_velocities.data_ptr(), self._push_count.data_ptr()
+            r.push_interval = int(self.push_interval)
+            r.push_offset = int(self.common_step_counter) - int(self._step_count)
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.base_pos_out, r.base_quat_out, r.base_vel_out = o["base_pos"].data_ptr(), o["base_quat"].data_ptr(), o["base_vel"].data_ptr()
@@ -392,14 +422,15 @@ class AnymalTerrainTask(RLTask):
             return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
         self.refresh_dof_state_tensors()
         self.refresh_body_state_tensors()
-        self.common_step_counter += 1
-        if self.common_step_counter % self.push_interval == 0:
+        self._advance_step_counter()  # common_step_counter += 1 (:418): it is _step_count + a constant, see the property
+        if not self.device_push and self.common_step_counter % self.push_interval == 0:
             self.push_robots()
-        self._step_count += 1
-        p, s, b, r = self._params(), self._state(), self._buffers(), self._reset_io(noise_u=noise_u)
+        p, s, b, r = self._params(), self._state(), self._buffers(), self._reset_io(noise_u=noise_u, push=True)
         rc = _lib.load().oige_anymal_post_physics(C.byref(p), C.byref(s), C.byref(b), C.byref(r), self._num_envs,
                                                   _lib.current_stream(self.obs_buf.device))
         _lib.check(rc, "oige_anymal_post_physics")
+        if r.push_velocities:  # :450 with a device-side count: N on a push step, 0 otherwise
+            self._anymals.set_velocities(self.base_velocities, indices=self._all_indices, count=self._push_count)
         self.reset_buf = self._reset_bool  # bool, as the reference rebinds it (:465)
         self._apply_reset_writes(None)
         self._bind_extras()

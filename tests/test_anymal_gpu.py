@@ -215,3 +215,56 @@ def test_full_size_properties():
     assert int(task.progress_buf[ids].sum().item()) == 0
     assert_equal(task.progress_buf[~task.reset_buf], (st["progress"] + 1)[~task.reset_buf.cpu()], "progress of live envs")
     assert bool((task.rew_buf >= 0).all())
+
+
+def test_device_side_push_robots_over_several_steps():
+    """push_robots (:419-420, :446-450) inside the post kernel: on steps where common_step_counter % push_interval == 0 the
+    base xy velocities of EVERY env become U(-1,1) (Philox stream 7) before anything reads them, so that step's
+    observations and reward already see the push; on the other steps nothing is touched and the setter's count is 0."""
+    n = 300
+    env, task, st = _loaded(n)
+    assert task.device_push and task.graph_capturable is True
+    task.push_interval = 3
+    task.common_step_counter = 1  # so that the 2nd and the 5th step push
+    spec = _spec(task)
+    s, b = _oracle_inputs(task, st)
+    hs, origins = task.height_samples.cpu(), task.terrain_origins.cpu()
+    seed = task._rand_seed
+    pushes = []
+    for it in range(5):
+        step = task._step_count + 1
+        pushing = (task.common_step_counter + 1) % 3 == 0
+        pushes.append(pushing)
+        if pushing:
+            u = torch.from_numpy(philox.uniforms(np.arange(n), 2, seed, step, stream=7))
+            s.base_velocities[:, 0:2] = 2.0 * u + (-1.0)
+        env_ids, view = ao.post_physics(spec, b, s, hs, origins, draw=_philox_draws(seed, step), noise_u=_philox_noise(n, seed, step))
+        task.post_physics_step()
+        torch.cuda.synchronize()
+        assert int(task._push_count) == (n if pushing else 0)
+        _compare(task, b, env_ids, view, n)
+        assert_close(task._anymals.velocities, view["base_velocities"], "view velocities after push + reset setters", rtol=0, atol=0)
+        s = ao.AnymalState(view["base_pos"], view["base_quat"], view["base_velocities"], view["dof_pos"], view["dof_vel"],
+                           s.knee_contact, s.base_contact)
+    assert pushes == [False, True, False, False, True]
+
+
+def test_host_side_push_robots_is_still_there():
+    """device_push = False: the reference's host branch with torch's own draw (and no graph capture)."""
+    n = 64
+    env, task, st = _loaded(n)
+    task.device_push = False
+    assert task.graph_capturable is not True
+    task.push_interval = 2
+    torch.manual_seed(3)
+    want = 2.0 * torch.rand(n, 2, device=task.device) + (-1.0)
+    torch.manual_seed(3)
+    before = task._anymals.velocities.clone()
+    task.post_physics_step()  # common_step_counter 1: no push
+    task._anymals.velocities.copy_(before)
+    task.post_physics_step()  # 2: push
+    torch.cuda.synchronize()
+    assert task.common_step_counter == 2
+    resets = task.reset_buf.cpu()
+    keep = ~resets  # envs that reset this step got their base velocity rows from reset_idx afterwards
+    assert_close(task._anymals.velocities[:, 0:2].cpu()[keep], want.cpu()[keep], "pushed xy velocities", rtol=0, atol=0)

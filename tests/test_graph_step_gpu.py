@@ -17,7 +17,7 @@ from helpers import assert_equal  # noqa: E402
 pytestmark = pytest.mark.gpu
 CASES = [("Ant", 4096), ("Ant", 300), ("Humanoid", 1000), ("ShadowHand", 1000), ("AllegroHand", 700), ("Anymal", 1000), ("Quadcopter", 900),
          ("BallBalance", 900), ("Ingenuity", 900), ("Crazyflie", 900), ("FrankaCabinet", 900), ("TomoSPCCabinet", 500),
-         ("TomoDJnewhandTendonCabinet", 500)]
+         ("TomoDJnewhandTendonCabinet", 500), ("AnymalTerrain", 700)]
 
 
 def _views(task):
@@ -86,6 +86,8 @@ def test_graph_replay_equals_eager_steps(name, n):
     acts = [(torch.rand(n, A, generator=g) * 2 - 1).to("cuda:0") for _ in range(6)]
     static = acts[0].clone()
     te, tg = eager.task, graph.task
+    if name == "AnymalTerrain":          # push_robots on every other step: the device-side branch must replay, not freeze
+        te.push_interval = tg.push_interval = 2
     torch.manual_seed(99)
     tg.capture_step(static)              # runs step 0 eagerly (warm-up), captures the step
     torch.manual_seed(99)
@@ -126,7 +128,8 @@ def test_capture_needs_the_sync_free_path_and_a_capturable_task():
     with pytest.raises(RuntimeError, match="sync-free"):
         b.task.capture_step(b.actions)
     t = _build("AnymalTerrain", 64, False)
-    with pytest.raises(NotImplementedError, match="host-side branches"):
+    t.task.device_push = False           # the reference's host-side push_robots branch cannot be frozen into a graph
+    with pytest.raises(NotImplementedError, match="host-side branch"):
         t.task.capture_step(t.actions)
 
 
