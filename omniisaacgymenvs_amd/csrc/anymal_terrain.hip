@@ -132,7 +132,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void anymal_scan_norm_kernel(int32_t*
   __shared__ int wave_tot[SCAN_THREADS / WAVE];
   __shared__ double part[SCAN_THREADS / WAVE];
   if (blockIdx.x == 0) {
-    scan_groups_body(reset_ws, n_groups, reset_ws + padded, wave_tot);
+    scan_groups_body(reset_ws, n_groups, tiles, reset_ws + padded, wave_tot);
     return;
   }
   double acc = 0.0;

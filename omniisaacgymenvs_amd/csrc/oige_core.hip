@@ -32,19 +32,19 @@ __global__ __launch_bounds__(GROUP) void count_flags_kernel(const int64_t* __res
 
 // One workgroup of 1024 threads; thread i owns a contiguous run of groups (oige_scan.hpp).
 __global__ __launch_bounds__(SCAN_THREADS) void scan_groups_kernel(const int32_t* __restrict__ tile_counts,
-                                                                   int64_t n_groups,
+                                                                   int64_t n_groups, int64_t n_tiles,
                                                                    int32_t* __restrict__ group_offsets) {
   __shared__ int wave_tot[SCAN_THREADS / WAVE];
-  scan_groups_body(tile_counts, n_groups, group_offsets, wave_tot);
+  scan_groups_body(tile_counts, n_groups, n_tiles, group_offsets, wave_tot);
 }
 
 // Two independent scans (a task's second compaction: goal resets, target resets, the noise interval) in one launch:
 // workgroup b scans workspace b.  Each is a one-workgroup, latency-bound pass; side by side they cost one.
 __global__ __launch_bounds__(SCAN_THREADS) void scan_groups2_kernel(int32_t* __restrict__ ws_a, int32_t* __restrict__ ws_b,
-                                                                    int64_t n_groups, int64_t padded) {
+                                                                    int64_t n_groups, int64_t n_tiles, int64_t padded) {
   __shared__ int wave_tot[SCAN_THREADS / WAVE];
   int32_t* ws = blockIdx.x == 0 ? ws_a : ws_b;
-  scan_groups_body(ws, n_groups, ws + padded, wave_tot);
+  scan_groups_body(ws, n_groups, n_tiles, ws + padded, wave_tot);
 }
 
 __global__ __launch_bounds__(GROUP) void emit_ids_kernel(const int64_t* __restrict__ flags, int64_t n,
@@ -81,12 +81,12 @@ int launch_count_flags(const int64_t* flags, int64_t n, int32_t* ws, hipStream_t
 
 int launch_scan_groups(int64_t n, int32_t* ws, hipStream_t stream) {
   const int64_t G = num_groups(n);
-  hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, ws, G, ws + padded_tiles(n));
+  hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(SCAN_THREADS), 0, stream, ws, G, num_tiles(n), ws + padded_tiles(n));
   return check_launch("scan_groups_kernel");
 }
 
 int launch_scan_groups2(int64_t n, int32_t* ws_a, int32_t* ws_b, hipStream_t stream) {
-  hipLaunchKernelGGL(scan_groups2_kernel, dim3(2), dim3(SCAN_THREADS), 0, stream, ws_a, ws_b, num_groups(n), padded_tiles(n));
+  hipLaunchKernelGGL(scan_groups2_kernel, dim3(2), dim3(SCAN_THREADS), 0, stream, ws_a, ws_b, num_groups(n), num_tiles(n), padded_tiles(n));
   return check_launch("scan_groups2_kernel");
 }
 

@@ -7,7 +7,16 @@ namespace oige {
 
 constexpr int SCAN_THREADS = 1024;
 
-__device__ __forceinline__ void scan_groups_body(const int32_t* __restrict__ tile_counts, int64_t n_groups,
+// sum of a group's four tile counts; slots past the last real tile (the padding of the last group) count as zero whatever
+// they hold, so the scan does not depend on anyone having zeroed them
+__device__ __forceinline__ int group_count(const int4* __restrict__ c4, int64_t g, int64_t n_tiles) {
+  const int4 c = c4[g];
+  const int64_t t0 = g * GROUP_TILES;
+  if (t0 + GROUP_TILES <= n_tiles) return (c.x + c.y) + (c.z + c.w);
+  return ((t0 < n_tiles ? c.x : 0) + (t0 + 1 < n_tiles ? c.y : 0)) + ((t0 + 2 < n_tiles ? c.z : 0) + (t0 + 3 < n_tiles ? c.w : 0));
+}
+
+__device__ __forceinline__ void scan_groups_body(const int32_t* __restrict__ tile_counts, int64_t n_groups, int64_t n_tiles,
                                                  int32_t* __restrict__ group_offsets, int* wave_tot /* [SCAN_THREADS / WAVE] in LDS */) {
   const int tid = threadIdx.x;
   const int64_t per = (n_groups + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -15,10 +24,7 @@ __device__ __forceinline__ void scan_groups_body(const int32_t* __restrict__ til
   const int64_t g1 = g0 + per < n_groups ? g0 + per : n_groups;
   const int4* c4 = reinterpret_cast<const int4*>(tile_counts);  // GROUP_TILES == 4 counts per group
   int mine = 0;
-  for (int64_t g = g0; g < g1; ++g) {
-    const int4 c = c4[g];
-    mine += (c.x + c.y) + (c.z + c.w);
-  }
+  for (int64_t g = g0; g < g1; ++g) mine += group_count(c4, g, n_tiles);
   // inclusive scan of `mine` across the wave, then across waves
   int incl = mine;
 #pragma unroll
@@ -34,8 +40,7 @@ __device__ __forceinline__ void scan_groups_body(const int32_t* __restrict__ til
   int run = base + incl - mine;  // exclusive prefix at g0
   for (int64_t g = g0; g < g1; ++g) {
     group_offsets[g] = run;
-    const int4 c = c4[g];
-    run += (c.x + c.y) + (c.z + c.w);
+    run += group_count(c4, g, n_tiles);
   }
   if (tid == SCAN_THREADS - 1) {
     int total = 0;

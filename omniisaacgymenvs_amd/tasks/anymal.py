@@ -164,7 +164,7 @@ class AnymalTask(RLTask):
                                                        _lib.current_stream(self.obs_buf.device))
         _lib.check(rc, "oige_anymal_flat_post_physics")
         if stages & _lib.STAGE_DONE:
-            self._counts_key = (self.reset_buf.data_ptr(), self.reset_buf._version)
+            self._mark_counts(self.reset_buf)
 
     # ------------------------------------------------------------------ RLTask methods
     def get_observations(self) -> dict:
@@ -225,7 +225,7 @@ class AnymalTask(RLTask):
             num = int(o["count"].item())
             if num > 0:
                 self.reset_idx(o["env_ids"][:num].clone())
-        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key and not self._capturing:
+        elif self._counts_valid(self.reset_buf):
             flags |= _lib.PRE_COUNTS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS

@@ -147,7 +147,7 @@ class BallBalanceTask(RLTask):
                                                         _lib.current_stream(self.obs_buf.device))
         _lib.check(rc, "oige_ball_balance_post_physics")
         if stages & _lib.STAGE_DONE:
-            self._counts_key = (self.reset_buf.data_ptr(), self.reset_buf._version)
+            self._mark_counts(self.reset_buf)
 
     # ------------------------------------------------------------------ RLTask methods
     def get_observations(self) -> dict:
@@ -210,7 +210,7 @@ class BallBalanceTask(RLTask):
             if num > 0:
                 ids = o["env_ids"][:num].clone()
                 self.reset_idx(ids)
-        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key and not self._capturing:
+        elif self._counts_valid(self.reset_buf):
             flags |= _lib.PRE_COUNTS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS

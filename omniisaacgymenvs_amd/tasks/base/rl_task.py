@@ -211,10 +211,27 @@ class RLTask:
         self._graph_post.replay()
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
+    # ------------------------------------------------------------------ OIGE_PRE_COUNTS_VALID bookkeeping
+    # The post kernels leave the per-tile counts of the reset flags they wrote; the next pre_physics_step may skip its
+    # recount only while those flags are untouched.  The key holds the flag TENSORS (not their addresses: a rebound
+    # reset_buf is a different object even when the allocator hands the old address out again, and holding the old one
+    # keeps its memory from being recycled) and their torch version counters.  Writers torch cannot see (another library
+    # writing through the raw pointer) must set ``task._counts_key = None`` themselves.
+    _counts_key = None
+
+    def _mark_counts(self, *flag_bufs) -> None:
+        self._counts_key = tuple((b, b._version) for b in flag_bufs)
+
+    def _counts_valid(self, *flag_bufs) -> bool:
+        k = self._counts_key
+        return (k is not None and not self._capturing and len(k) == len(flag_bufs)
+                and all(t is b and v == b._version for (t, v), b in zip(k, flag_bufs)))
+
     # ------------------------------------------------------------------ RL interface
     def reset(self) -> None:
         """Flag every env for reset (:274-276; rebinds, as the reference does)."""
         self.reset_buf = torch.ones_like(self.reset_buf)
+        self._counts_key = None
 
     def post_physics_step(self):
         """progress += 1, then obs -> states -> metrics -> done -> extras (:289-298).

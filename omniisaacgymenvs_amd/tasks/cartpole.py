@@ -80,7 +80,7 @@ class CartpoleTask(RLTask):
         )
         _lib.check(rc, "oige_cartpole_post_physics")
         if stages & _lib.STAGE_DONE:
-            self._counts_key = (self.reset_buf.data_ptr(), self.reset_buf._version)
+            self._mark_counts(self.reset_buf)
 
     # ------------------------------------------------------------------ RLTask methods
     def get_observations(self) -> dict:
@@ -131,7 +131,7 @@ class CartpoleTask(RLTask):
             num = int(o["count"].item())
             if num > 0:
                 self.reset_idx(o["env_ids"][:num].clone())
-        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key and not self._capturing:
+        elif self._counts_valid(self.reset_buf):
             flags |= _lib.PRE_COUNTS_VALID
         p, b, r = self._params(), self._buffers(), self._reset_io()
         rc = _lib.load().oige_cartpole_pre_physics(

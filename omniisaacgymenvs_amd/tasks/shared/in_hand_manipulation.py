@@ -243,8 +243,7 @@ class InHandManipulationTask(RLTask):
                                                     _lib.current_stream(self.obs_buf.device))
             _lib.check(rc, "oige_hand_post_physics")
         if stages & _lib.STAGE_METRICS:
-            self._counts_key = (self.reset_buf.data_ptr(), self.reset_buf._version,
-                                self.reset_goal_buf.data_ptr(), self.reset_goal_buf._version)
+            self._mark_counts(self.reset_buf, self.reset_goal_buf)
 
     # ------------------------------------------------------------------ RLTask methods
     def get_observations(self):
@@ -355,9 +354,7 @@ class InHandManipulationTask(RLTask):
             if ne > 0:
                 self.reset_idx(env_ids)
         else:
-            key = (self.reset_buf.data_ptr(), self.reset_buf._version,
-                   self.reset_goal_buf.data_ptr(), self.reset_goal_buf._version)
-            if key == self._counts_key and not self._capturing:
+            if self._counts_valid(self.reset_buf, self.reset_goal_buf):
                 flags |= _lib.PRE_COUNTS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS  # the wrapper's clamp (vec_env_rlgames.py:77), folded into the kernel

@@ -168,7 +168,7 @@ class LocomotionTask(RLTask):
         )
         _lib.check(rc, "oige_locomotion_post_physics")
         if stages & _lib.STAGE_DONE:
-            self._counts_key = (self.reset_buf.data_ptr(), self.reset_buf._version)
+            self._mark_counts(self.reset_buf)
 
     # ------------------------------------------------------------------ RLTask methods
     def get_observations(self) -> dict:
@@ -249,7 +249,7 @@ class LocomotionTask(RLTask):
             num = int(o["count"].item())
             if num > 0:
                 self.reset_idx(o["env_ids"][:num].clone())
-        elif (self.reset_buf.data_ptr(), self.reset_buf._version) == self._counts_key and not self._capturing:
+        elif self._counts_valid(self.reset_buf):
             flags |= _lib.PRE_COUNTS_VALID  # the DONE stage's tile counts still describe reset_buf (never baked into a graph)
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS  # the wrapper's clamp (vec_env_rlgames.py:77), folded into the kernel

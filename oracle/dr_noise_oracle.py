@@ -64,12 +64,14 @@ def apply_randomization(buffer: Tensor, reset_buf: Tensor, counter: Tensor, corr
     return buffer
 
 
-def philox_samples(p: Dict, n: int, width: int, seed: int, step: int, stream_id: int, kind: str) -> Tensor:
+def philox_samples(p: Dict, n: int, width: int, seed: int, step: int, stream_id: int, kind: str, row0: int = 0) -> Tensor:
     """(N,W) samples the sync-free kernel would use for EVERY element: element i takes word i % 4 of the block
-    with counter (i // 4, (4 + 2*stream_id + kind) << 16, step) -- csrc/dr_noise.hip noise_samples()."""
+    with counter (i // 4, (4 + 2*stream_id + kind) << 16, step) -- csrc/dr_noise.hip noise_samples().
+    ``row0``: the n rows are rows row0 .. row0 + n of a larger buffer (``row0 * width`` must be a multiple of 4)."""
     total = n * width
     nblk = (total + 3) // 4
-    gf = np.arange(nblk, dtype=np.uint64)
+    assert (row0 * width) % 4 == 0
+    gf = np.arange(nblk, dtype=np.uint64) + np.uint64(row0 * width // 4)
     tag = 4 + 2 * stream_id + (1 if kind == "on_interval" else 0)
     w = philox.philox4x32_10(gf & philox.MASK, (gf >> np.uint64(32)) | np.uint64(tag << 16), np.uint64(step & 0xFFFFFFFF),
                              np.uint64(step >> 32), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)

@@ -84,16 +84,24 @@ def test_post_physics_matches_oracle(cfg_name, n, fused):
     ho.post_physics(spec, s, b)
     obs, rew, reset, extras = task.post_physics_step()
     torch.cuda.synchronize()
-    assert bool(ok.all()) or n > 1000
+    masked = int((~ok).sum())  # rows within 1e-6 of a decision threshold: none expected in this seeded state
+    assert masked <= (0 if n <= 1000 else 4), f"{masked} of {n} rows inside the threshold mask"
+    cons_in = torch.tensor([2.5])  # what _loaded put there before the step
     assert_equal(reset[ok], b.reset_buf[ok], "reset_buf")
     assert_equal(task.reset_goal_buf[ok], b.reset_goal_buf[ok], "reset_goal_buf")
     assert_equal(task.progress_buf[ok], b.progress_buf[ok], "progress_buf")
     assert_close(obs, b.obs_buf, "obs_buf")
     assert_close(rew[ok], b.rew_buf[ok], "rew_buf")
     assert_close(task.successes[ok], b.successes[ok], "successes")
-    if bool(ok.all()):
+    if masked == 0:
         assert_close(task.consecutive_successes, b.consecutive_successes, "consecutive_successes")
         assert_close(extras["consecutive_successes"].reshape(1), b.consecutive_successes.mean().reshape(1), "extras")
+    # always: the reference's global tail (:522-529) on the flags and successes the GPU itself produced
+    av = float(torch.tensor(spec.av_factor, dtype=torch.float))
+    r_, s_ = task.reset_buf.cpu(), task.successes.cpu()
+    num, fin = torch.sum(r_), torch.sum(s_ * r_.float())
+    assert_close(task.consecutive_successes, torch.where(num > 0, av * fin / num + (1.0 - av) * cons_in, cons_in),
+                 "consecutive_successes from the GPU's own flags")
     if n >= 64:
         assert int(reset.sum().item()) > 0 and int(task.reset_goal_buf.sum().item()) > 0
     tiles = (n + 63) // 64

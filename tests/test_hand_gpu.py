@@ -67,6 +67,14 @@ def _oracle_buffers(task) -> ho.HandBuffers:
                           c(task.goal_rot), c(task.actions), c(task.prev_targets), c(task.cur_targets))
 
 
+def _cons_from(resets, successes, cons_in, av_factor):
+    """compute_hand_reward's global tail (in_hand_manipulation.py:522-529) on given flags / successes."""
+    av = float(torch.tensor(av_factor, dtype=torch.float))
+    num_resets = torch.sum(resets)
+    fin = torch.sum(successes * resets.float())
+    return torch.where(num_resets > 0, av * fin / num_resets + (1.0 - av) * cons_in, cons_in)
+
+
 def _threshold_mask(spec, s, b):
     """Envs whose oracle rot_dist / goal_dist sit within 1e-6 of a decision threshold may land on
     the other side in fp32 (SURVEY.md appendix A.3 flip-risk compares); they are excluded."""
@@ -88,7 +96,10 @@ def test_post_physics_matches_oracle(cfg_name, n, fused):
     ho.post_physics(spec, s, b)
     obs, rew, reset, extras = task.post_physics_step()
     torch.cuda.synchronize()
-    assert bool(ok.all()) or n > 1000
+    masked = int((~ok).sum())  # rows within 1e-6 of a decision threshold: none expected in this seeded state
+    assert masked <= (0 if n <= 1000 else 4), f"{masked} of {n} rows inside the threshold mask"
+    if masked:
+        print(f"[threshold mask] {cfg_name} n={n}: {masked} row(s) excluded from the flag comparison")
     assert_equal(reset[ok], b.reset_buf[ok], "reset_buf")
     assert_equal(task.reset_goal_buf[ok], b.reset_goal_buf[ok], "reset_goal_buf")
     assert_equal(task.progress_buf[ok], b.progress_buf[ok], "progress_buf")
@@ -97,9 +108,13 @@ def test_post_physics_matches_oracle(cfg_name, n, fused):
         assert_close(task.states_buf, b.states_buf, "states_buf")
     assert_close(rew[ok], b.rew_buf[ok], "rew_buf")
     assert_close(task.successes[ok], b.successes[ok], "successes")
-    if bool(ok.all()):
+    # the global reduction (:522-529) is always checked: against the oracle when no row is masked, and in any case against
+    # the reference's formula evaluated on the flags and successes the GPU itself produced
+    if masked == 0:
         assert_close(task.consecutive_successes, b.consecutive_successes, "consecutive_successes")
         assert_close(extras["consecutive_successes"].reshape(1), b.consecutive_successes.mean().reshape(1), "extras")
+    assert_close(task.consecutive_successes, _cons_from(task.reset_buf.cpu(), task.successes.cpu(), torch.tensor([2.5]), spec.av_factor),
+                 "consecutive_successes from the GPU's own flags")
     tiles = (n + 63) // 64
     pad = lambda t: torch.nn.functional.pad(t, (0, tiles * 64 - n)).view(tiles, 64).ne(0).sum(-1).int()
     assert_equal(task._reset_workspace[:tiles], pad(task.reset_buf.cpu()), "reset tile counts")

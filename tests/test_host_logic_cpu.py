@@ -100,3 +100,31 @@ def test_noise_terms_fold_their_parameters_like_python():
     assert noise_hip._term(p, "absent").enabled == 0
     with pytest.raises(Exception, match="not supported"):
         noise_hip._term({"on_reset": {"operation": "xor", "distribution": "uniform", "distribution_parameters": [0, 1]}}, "on_reset")
+
+
+def test_counts_valid_key_follows_the_tensor_not_its_address():
+    """OIGE_PRE_COUNTS_VALID keyed on (data_ptr, _version) can match a REBOUND reset_buf that landed on a recycled
+    address.  The key holds the tensor objects: a rebind, an in-place torch write or reset() invalidates it."""
+    import torch
+
+    from omniisaacgymenvs_amd.tasks.base.rl_task import RLTask
+
+    t = RLTask.__new__(RLTask)
+    t.reset_buf = torch.zeros(8, dtype=torch.int64)
+    goal = torch.zeros(8, dtype=torch.int64)
+    assert not t._counts_valid(t.reset_buf)          # nothing marked yet
+    t._mark_counts(t.reset_buf, goal)
+    assert t._counts_valid(t.reset_buf, goal)
+    assert not t._counts_valid(t.reset_buf)          # a different set of flag buffers
+    t.reset_buf[3] = 1                               # torch-side write: version moves
+    assert not t._counts_valid(t.reset_buf, goal)
+    t._mark_counts(t.reset_buf, goal)
+    old_ptr = t.reset_buf.data_ptr()
+    view = t.reset_buf.view(-1)                      # same storage, same address, same version -- another object
+    assert view.data_ptr() == old_ptr and not t._counts_valid(view, goal)
+    t._capturing = True                              # never baked into a graph
+    assert not t._counts_valid(t.reset_buf, goal)
+    t._capturing = False
+    assert t._counts_valid(t.reset_buf, goal)
+    t.reset()                                        # rl_task.py:274-276 rebinds reset_buf
+    assert t._counts_key is None and not t._counts_valid(t.reset_buf, goal)

@@ -132,3 +132,49 @@ def test_in_kernel_dr_noise_is_bit_identical_to_the_separate_launch(cfg, n):
         for k, (x, y) in enumerate(zip(a, b)):
             assert torch.equal(x, y), f"step {it} item {k}"
     assert float(runs[0][-1][8].abs().max()) > 0  # the correlated noise was refreshed at least once
+
+
+def test_in_kernel_dr_noise_at_full_size_against_the_oracle_on_a_slice():
+    """BASELINE config 4 as bench.py times it -- ShadowHand openai obs + full_state states with the observation noise applied
+    INSIDE hand_post_kernel -- at 1 M envs: a 4096-row slice from the middle of the batch against hand_oracle +
+    dr_noise_oracle (Philox samples keyed by the rows' position in the full buffer); flags bit-exact, floats within tolerance."""
+    n, r0, m = 1 << 20, (1 << 19) + 192, 4096
+    dr = copy.deepcopy(TASK_DEFAULTS["ShadowHandOpenAI_FF"]["domain_randomization"])
+    dr["randomize"] = True
+    env, task = make_task("ShadowHandOpenAI_FF", n, domain_randomization=dr)
+    st = workloads.hand_state(n, task._env_pos.cpu(), task.goal_pos.cpu(), task.hand_dof_lower_limits.cpu(),
+                              task.hand_dof_upper_limits.cpu(), device="cpu", seed=7)
+    workloads.load_hand_state(task, st)
+    r = task._dr_randomizer
+    sl = slice(r0, r0 + m)
+    cut = lambda t, k=1: t[r0 * k:(r0 + m) * k].clone()
+    spec = _spec(task)
+    s = ho.HandState(cut(st["object_pos"]), cut(st["object_rot"]), cut(st["object_vel"]), cut(st["ft_pos"], 5), cut(st["ft_rot"], 5),
+                     cut(st["ft_vel"], 5), cut(st["dof_pos"]), cut(st["dof_vel"]), cut(st["sensors"]), task._env_pos.cpu()[sl].clone())
+    c = lambda t: t[sl].detach().cpu().clone()
+    b = ho.HandBuffers(c(task.obs_buf), c(task.states_buf), c(task.rew_buf), c(task.reset_buf), c(task.reset_goal_buf),
+                       c(task.progress_buf), c(task.successes), task.consecutive_successes.cpu().clone(), c(task.goal_pos),
+                       c(task.goal_rot), c(task.actions), c(task.prev_targets), c(task.cur_targets))
+    ho.post_physics(spec, s, b)
+    params = dr["randomization_params"]["observations"]
+    clamped = torch.empty_like(task.obs_buf)
+    task.post_physics_step(obs_noise=r.fused_observations_args(task.obs_buf, clamped_out=clamped, clip=task.clip_obs))
+    torch.cuda.synchronize()
+    step, seed = r._observations_step, int(task._cfg["seed"])
+    tables = {k: dro.philox_samples(params[k], m, 42, seed, step, 0, k, row0=r0) for k in params}
+    cnt, cor = torch.zeros(m, dtype=torch.int), torch.zeros(m, 42)
+    dro.apply_randomization(b.obs_buf, b.reset_buf, cnt, cor, params, draw=lambda kind, ids: tables[kind][ids])
+    assert_equal(task.reset_buf[sl], b.reset_buf, "reset_buf slice")
+    assert_equal(task.reset_goal_buf[sl], b.reset_goal_buf, "reset_goal_buf slice")
+    assert_equal(task.progress_buf[sl], b.progress_buf, "progress_buf slice")
+    assert int(b.reset_buf.sum()) > 0  # the slice refreshes correlated noise
+    assert_close(task.obs_buf[sl], b.obs_buf, "noised obs slice")
+    assert_close(clamped[sl], torch.clamp(b.obs_buf, -task.clip_obs, task.clip_obs), "clamped obs slice")
+    assert_close(task.states_buf[sl], b.states_buf, "states slice")
+    assert_close(task.rew_buf[sl], b.rew_buf, "rew slice")
+    assert_close(r._observations_correlated_noise[sl], cor, "correlated noise slice")
+    assert_equal(r._observations_counter_buffer[sl], cnt, "noise counter slice")
+    # the rest of the batch: every env with a reset flag has fresh (non-zero) correlated noise, the others still have none
+    flagged = task.reset_buf != 0
+    nz = r._observations_correlated_noise.abs().sum(dim=1) > 0
+    assert torch.equal(nz, flagged)
