@@ -149,12 +149,17 @@ __global__ __launch_bounds__(SCAN_THREADS) void anymal_scan_norm_kernel(int32_t*
 }
 
 // ------------------------------------------------------------------ main
-// LDS row of one env in the head kernel: the 36 head columns of the observation and the 12 action columns (obs
-// 176:188), padded to 13 float4 (odd: per-lane 16-byte row accesses are bank-conflict free).  last_actions,
-// last_dof_vel and torques only feed three sums: each lane reads its own 48-byte rows of those straight from global.
-// The 140 height-scan columns never touch this tile: the scan kernel writes them.
-constexpr int ARW = 52;
-constexpr int L_DPOS = 12, L_DVEL = 24, L_ACT = 36;
+// LDS row of one env in the head kernel: 36 floats = 9 float4 (odd: per-lane 16-byte row accesses are bank-conflict
+// free).  Columns 12:36 take dof_pos / dof_vel (raw, then scaled: observation columns 12:36); columns 0:12 first hold
+// the env's actions (read by the action-rate sum and the last_actions copy) and are then overwritten by the 12 head
+// columns of the observation, so the row ends up as observation columns 0:36.  The action columns of the observation
+// (176:188) are re-read from `actions` in the epilogue (L2-hot).  r01 kept all 48 columns (+ 4 of padding): 13.5 KB of LDS
+// per one-wave workgroup = 11 waves per CU, so the 4096 tiles of 256 K envs ran as 1.45 rounds; 9.4 KB fits all 16
+// waves the 124 VGPRs allow, i.e. every tile is resident at once.
+// last_actions, last_dof_vel and torques only feed three sums: each lane reads its own 48-byte rows of those straight
+// from global.  The 140 height-scan columns never touch this tile: the scan kernel writes them.
+constexpr int ARW = 36;
+constexpr int L_ACT = 0, L_DPOS = 12, L_DVEL = 24;
 constexpr int AP4 = AP / 4;  // 35 float4 of scan columns per env
 // Pose record the head kernel leaves per env for the scan kernel, after the RW * tiles + 4 reduction floats of
 // reduce_workspace: (yaw quat w, z, base x, y), (base z - 0.5, -, -, -).  (Routing the 48 head / action columns through
@@ -173,6 +178,17 @@ __device__ __forceinline__ float div_by_const(float x, float h, float inv) {
 }
 
 __device__ __forceinline__ float4 lds4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4_plain(float* p, const float4 v) { *reinterpret_cast<float4*>(p) = v; }
+#ifdef OIGE_ANYMAL_HEAD_NT
+#define ANYMAL_HEAD_ST4(p, v) st4_stream((p), (v))
+#else
+#define ANYMAL_HEAD_ST4(p, v) st4_plain((p), (v))
+#endif
+#ifdef OIGE_ANYMAL_SCAN_PLAIN
+#define ANYMAL_SCAN_ST4(p, v) st4_plain((p), (v))
+#else
+#define ANYMAL_SCAN_ST4(p, v) st4_stream((p), (v))
+#endif
 
 // uniform noise of four consecutive observation columns starting at flat float offset `off` (:438-439)
 __device__ __forceinline__ void anymal_noise4(const oige_anymal_reset_io& r, uint64_t step, int64_t off, float (&uu)[4]) {
@@ -190,7 +206,7 @@ __device__ __forceinline__ void anymal_noise4(const oige_anymal_reset_io& r, uin
 template <bool FULLTILE>
 __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __restrict__ lds, int64_t t, int nv) {
   float* rows = lds;                         // 64 x 52
-  float* s_ns = lds + TILE * ARW;            // 48: noise_scale_vec (:157-171) by LDS column (head 0:36, actions 36:48)
+  float* s_ns = lds + TILE * ARW;            // noise_scale_vec (:157-171) of observation columns 0:36 (48 slots kept)
   const oige_anymal_params& p = a.p;
   const int tid = threadIdx.x;               // one wavefront per tile
   const uint64_t noise_step = step_of(a.r);  // read once: by value, or the device counter of a replayed graph
@@ -469,38 +485,49 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
     }
   }
   if (!step) return;  // uniform across the workgroup
+  // The action columns of the observation (176:188) are a copy of `actions` (their noise scale is zero, :170: obs +
+  // (2u - 1) * 0 is obs, no draw).  The tile's actions are fetched again here, lane-linear and L2-hot, BEFORE the epilogue's
+  // first store: a load issued after a store waits for that store's round trip (loads and stores share vmcnt).
+  Chunk<AD> c_act;
+  load_chunk<AD, FULLTILE>(c_act, a.b.actions + env0 * AD, nv * AD);
   __syncthreads();
 
-  // ---- D1: head (cols 0:36) and actions (cols 176:188) of every row -> obs_buf with their noise
+  // ---- D1: head (cols 0:36) of every row -> obs_buf with its noise; then the action columns
   {
-    constexpr int HF4 = TILE * 12;  // 9 + 3 float4 per env
+    constexpr int HF4 = TILE * 9;  // 9 float4 per env
 #pragma unroll
     for (int it = 0; it < HF4 / WAVE; ++it) {
       const int f = it * WAVE + tid;
-      const int e = f / 12, j = f - 12 * e;
+      const int e = f / 9, j = f - 9 * e;
       if (!FULLTILE && e >= nv) continue;
-      const int lcol = 4 * j;                            // LDS column: head 0:36, actions 36:48
-      const int ocol = j < 9 ? lcol : 176 + (lcol - 36);  // observation column
-      float4 v = lds4(rows + e * ARW + lcol);
-      const int64_t off = (env0 + e) * AO + ocol;
+      const int col = 4 * j;  // LDS column == observation column
+      float4 v = lds4(rows + e * ARW + col);
+      const int64_t off = (env0 + e) * AO + col;
 #ifndef OIGE_EXP_NO_NOISE
       if (p.add_noise) {
         float uu[4];
         anymal_noise4(a.r, noise_step, off, uu);
-        const float4 sc = lds4(s_ns + lcol);
+        const float4 sc = lds4(s_ns + col);
         v.x = v.x + (2.0f * uu[0] - 1.0f) * sc.x;
         v.y = v.y + (2.0f * uu[1] - 1.0f) * sc.y;
         v.z = v.z + (2.0f * uu[2] - 1.0f) * sc.z;
         v.w = v.w + (2.0f * uu[3] - 1.0f) * sc.w;
       }
 #endif
-      st4_stream(a.b.obs_buf + off, v);  // write-once stream: non-temporal (oige_tile.hpp)
+      ANYMAL_HEAD_ST4(a.b.obs_buf + off, v);
+    }
+#pragma unroll
+    for (int it = 0; it < Chunk<AD>::ITERS; ++it) {  // 12 % 4 == 0: a float4 of the run never straddles two envs
+      const int f = it * WAVE + tid;
+      const int e = f / 3, c = f - 3 * e;
+      if (!FULLTILE && e >= nv) continue;
+      ANYMAL_HEAD_ST4(a.b.obs_buf + (env0 + e) * AO + 176 + 4 * c, c_act.v[it]);
     }
   }
 }
 
 __global__ __launch_bounds__(WAVE) void anymal_head_kernel(const AnymalPost a) {
-  __shared__ __align__(16) float lds[TILE * ARW + 48];
+  __shared__ __align__(16) float lds[TILE * ARW + 48];  // rows + noise scales by column
   const int64_t t = blockIdx.x;
   const int64_t left = a.n - t * TILE;
   if (left >= TILE)
@@ -655,7 +682,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
           v.w = v.w + (2.0f * uu[3] - 1.0f) * nscale;
         }
 #endif
-        st4_stream(a.b.obs_buf + off, v);  // write-once stream: non-temporal (oige_tile.hpp)
+        ANYMAL_SCAN_ST4(a.b.obs_buf + off, v);
       }
       cursor_advance(fe, fk, 7, 11, AP4);  // the wave's next chunk: +4 * 64 float4 = 7 * 35 + 11
     }
