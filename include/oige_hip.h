@@ -382,6 +382,8 @@ typedef struct oige_anymal_state {
   const float* base_contact;     /* (N,3)  _base.get_net_contact_forces */
   const int16_t* height_samples; /* (hs_rows, hs_cols) int16 (:196-198) */
   const float* terrain_origins;  /* (env_rows, env_cols, 3) (:241) */
+  const int16_t* height_min;     /* NULL, or (hs_rows, hs_cols) from oige_anymal_height_min(height_samples): one gather per
+                                    scan point instead of the two of :598-600 */
 } oige_anymal_state;
 
 typedef struct oige_anymal_buffers {
@@ -437,6 +439,12 @@ typedef struct oige_anymal_reset_io {
   int64_t push_interval;    /* :131-133 int(pushInterval_s / dt + 0.5) */
   int64_t push_offset;
 } oige_anymal_reset_io;
+
+/* get_heights (:598-600) reads height_samples[px, py] and height_samples[px + 1, py + 1] and keeps the smaller: that
+ * minimum depends on the map alone, so it is tabulated once per map: out[r, c] = min(h[r, c], h[r + 1, c + 1]) for
+ * r <= rows - 2, c <= cols - 2 (the only cells the clipped indices can address), h[r, c] elsewhere.  Integer min, then
+ * the same `* vertical_scale`: bit-identical heights, half the gathers (the scan kernel's address unit was 80 % busy). */
+int oige_anymal_height_min(const int16_t* height_samples, int32_t hs_rows, int32_t hs_cols, int16_t* out, oige_stream_t stream);
 
 /* One decimation sub-step of pre_physics_step (:398-403):
  * torques = clip(Kp*(action_scale*actions + default_dof_pos - dof_pos) - Kd*dof_vel, -80, 80)   */

@@ -138,7 +138,7 @@ class AnymalParams(C.Structure):
 class AnymalState(C.Structure):
     _fields_ = [(n, _fp) for n in (
         "base_pos", "base_quat", "base_velocities", "dof_pos", "dof_vel", "knee_contact", "base_contact",
-        "height_samples", "terrain_origins")]
+        "height_samples", "terrain_origins", "height_min")]
 
 
 class AnymalBuffers(C.Structure):
@@ -425,6 +425,7 @@ SIGNATURES = {
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
     "oige_dr_noise_count": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_dr_noise_apply": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
+    "oige_anymal_height_min": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "oige_anymal_torques": (C.c_int, [C.POINTER(AnymalParams), _P, _P, _P, _P, C.c_int64, _P]),
     "oige_anymal_post_physics": (C.c_int, [C.POINTER(AnymalParams), C.POINTER(AnymalState), C.POINTER(AnymalBuffers),
                                            C.POINTER(AnymalResetIO), C.c_int64, _P]),

@@ -52,6 +52,16 @@ __device__ __forceinline__ float wave_sum_ff(float v) {
   return v;
 }
 
+// ------------------------------------------------------------------ min(h[r, c], h[r + 1, c + 1]) per map cell
+__global__ __launch_bounds__(256) void anymal_height_min_kernel(const int16_t* __restrict__ h, int rows, int cols,
+                                                                int16_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  const int16_t v = h[i];
+  out[i] = (r + 1 < rows && c + 1 < cols) ? (v < h[i + cols + 1] ? v : h[i + cols + 1]) : v;
+}
+
 // ------------------------------------------------------------------ PD torques (:398-403)
 __global__ __launch_bounds__(256) void anymal_torques_kernel(const oige_anymal_params p, const float* __restrict__ actions,
                                                              const float* __restrict__ dof_pos,
@@ -613,6 +623,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
   const float hscale = p.horizontal_scale, hinv = 1.0f / p.horizontal_scale;
   const float nscale = p.noise_scales[5];
   const v2f border = {p.border_size, p.border_size};
+  const char* hmin = reinterpret_cast<const char*>(a.s.height_min);  // uniform: NULL -> the reference's two gathers
   const int wave = tid >> 6, lane = tid & (WAVE - 1);
   constexpr int NW = ANT / WAVE;
   float* strip = s_strip + wave * 256;
@@ -628,7 +639,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
 #pragma unroll
     for (int g = 0; g < ANG; ++g) {
       const float4 kk = lds4(s_k + 4 * pk);  // hx, hy, AB offset, CD offset
-      const char* eb = reinterpret_cast<const char*>(s_env + pe * AER);
+      const char* eb = reinterpret_cast<const char*>(s_env) + __mul24(pe, AER * 4);  // (v_mul_lo_u32 is quarter rate)
       const float2 ab = *reinterpret_cast<const float2*>(eb + __float_as_int(kk.z));
       const float2 cd = *reinterpret_cast<const float2*>(eb + __float_as_int(kk.w));
       const float4 pp = *reinterpret_cast<const float4*>(eb + 4 * AE_POS);  // base x, y, z - 0.5
@@ -654,8 +665,16 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
       h1[g] = (int16_t)idx[g];
       h2[g] = (int16_t)(idx[g] >> 3);
 #else
-      h1[g] = a.s.height_samples[idx[g]];
-      h2[g] = a.s.height_samples[idx[g] + hs_cols + 1];
+      // unsigned 32-bit element offsets: the gathers take the table's base from scalar registers and the offset as it
+      // is (no sign extension, no 64-bit address arithmetic per lane)
+      const uint32_t o1 = 2u * (uint32_t)idx[g], o2 = o1 + 2u * (uint32_t)(hs_cols + 1);  // byte offsets (the map is < 2 GiB)
+      if (hmin) {  // min(h[px, py], h[px + 1, py + 1]) tabulated per map: one gather (oige_anymal_height_min)
+        h1[g] = h2[g] = *reinterpret_cast<const int16_t*>(hmin + o1);
+      } else {
+        const char* hb = reinterpret_cast<const char*>(a.s.height_samples);
+        h1[g] = *reinterpret_cast<const int16_t*>(hb + o1);
+        h2[g] = *reinterpret_cast<const int16_t*>(hb + o2);
+      }
 #endif
     }
 #pragma unroll
@@ -757,6 +776,15 @@ __global__ __launch_bounds__(1024) void anymal_extras_kernel(const AnymalPost a)
 using namespace oige;
 
 extern "C" {
+
+int oige_anymal_height_min(const int16_t* height_samples, int32_t hs_rows, int32_t hs_cols, int16_t* out, oige_stream_t stream) {
+  OIGE_REQUIRE(height_samples && out && height_samples != out, "anymal_height_min: null or aliased pointer");
+  OIGE_REQUIRE(hs_rows >= 2 && hs_cols >= 2 && (int64_t)hs_rows * hs_cols < ((int64_t)1 << 30), "anymal_height_min: bad map dimensions");
+  const int64_t total = (int64_t)hs_rows * hs_cols;
+  hipLaunchKernelGGL(anymal_height_min_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, height_samples,
+                     (int)hs_rows, (int)hs_cols, out);
+  return check_launch("anymal_height_min_kernel");
+}
 
 int oige_anymal_torques(const oige_anymal_params* params, const float* actions, const float* dof_pos,
                         const float* dof_vel, float* torques_out, int64_t num_envs, oige_stream_t stream) {

@@ -292,8 +292,25 @@ class AnymalTerrainTask(RLTask):
         s.dof_pos, s.dof_vel = self.dof_pos.data_ptr(), self.dof_vel.data_ptr()
         s.knee_contact, s.base_contact = knee.data_ptr(), base.data_ptr()
         s.height_samples, s.terrain_origins = self.height_samples.data_ptr(), self.terrain_origins.data_ptr()
+        if self.use_height_min:
+            s.height_min = self._height_min_table().data_ptr()
         self._live_state = (knee, base)
         return s
+
+    # get_heights keeps min(h[px, py], h[px + 1, py + 1]) (:598-600): tabulated once per map, one gather per scan point
+    use_height_min = True
+
+    def _height_min_table(self) -> torch.Tensor:
+        """(hs_rows, hs_cols) int16 from ``oige_anymal_height_min``; rebuilt when ``height_samples`` is rebound or edited."""
+        hs = self.height_samples
+        key = (hs, hs._version)
+        cached = getattr(self, "_height_min_key", None)
+        if cached is None or cached[0] is not key[0] or cached[1] != key[1]:
+            out = torch.empty_like(hs)
+            _lib.check(_lib.load().oige_anymal_height_min(hs.data_ptr(), hs.shape[0], hs.shape[1], out.data_ptr(),
+                                                          _lib.current_stream(hs.device)), "oige_anymal_height_min")
+            self._height_min, self._height_min_key = out, key
+        return self._height_min
 
     def _buffers(self) -> _lib.AnymalBuffers:
         n = self._num_envs

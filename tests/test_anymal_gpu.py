@@ -268,3 +268,26 @@ def test_host_side_push_robots_is_still_there():
     resets = task.reset_buf.cpu()
     keep = ~resets  # envs that reset this step got their base velocity rows from reset_idx afterwards
     assert_close(task._anymals.velocities[:, 0:2].cpu()[keep], want.cpu()[keep], "pushed xy velocities", rtol=0, atol=0)
+
+
+def test_height_min_table_is_the_reference_minimum_and_changes_nothing():
+    """oige_anymal_height_min tabulates min(h[px, py], h[px + 1, py + 1]) (:598-600) once per map; the step with the table
+    (one gather per scan point) is bit-identical to the step with the reference's two gathers."""
+    n = 700
+    outs = []
+    for use in (True, False):
+        env, task, st = _loaded(n)
+        task.use_height_min = use
+        task.post_physics_step()
+        torch.cuda.synchronize()
+        outs.append((task.obs_buf.clone(), task.rew_buf.clone(), task.reset_buf.clone()))
+        if use:
+            h = task.height_samples
+            want = h.clone()
+            want[:-1, :-1] = torch.minimum(h[:-1, :-1], h[1:, 1:])
+            assert_equal(task._height_min, want, "height_min table")
+            assert task._height_min_table() is task._height_min          # cached
+            task.height_samples = h.clone()                              # a rebound map gets a new table
+            assert task._height_min_table() is not None and task._height_min_key[0] is task.height_samples
+    for a, b, what in zip(outs[0], outs[1], ("obs_buf", "rew_buf", "reset_buf")):
+        assert_equal(a, b, what)
