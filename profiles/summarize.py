@@ -73,7 +73,7 @@ def main() -> None:
     # (AnymalTerrain's post_physics_step is several kernels: their bytes are summed, as bench.py times them together)
     dominant = {"Ant": ["locomotion_post_kernel"], "Humanoid": ["locomotion_post_kernel"], "ShadowHand": ["hand_post_kernel"],
                 "AnymalTerrain": ["anymal_head_kernel", "anymal_scan_kernel", "anymal_flags_kernel", "anymal_extras_kernel",
-                                  "anymal_command_norm_kernel", "scan_groups_kernel"],
+                                  "anymal_scan_norm_kernel"],
                 "Anymal": ["anymal_flat_post_kernel"], "AllegroHand": ["allegro_post_kernel"],
                 "Quadcopter": ["quadcopter_post_kernel"], "BallBalance": ["ball_balance_post_kernel"],
                 "Ingenuity": ["ingenuity_post_kernel"], "Crazyflie": ["crazyflie_post_kernel"],
