@@ -314,9 +314,29 @@ struct LocoPre {
 // reset_idx for env `i` landing in compacted row `k` (locomotion.py:133-158)
 // STAGE: the DOF rows go to the caller instead of HBM (dof_pos into the LDS row `stage_pos`, dof_vel into `qv_out`), which then
 // writes the group's compacted rows as one lane-linear run
+// the rows reset_idx reads for env i: fetched apart from the arithmetic so that a caller can issue them with its other loads
+// (a load issued after a store waits for that store's round trip: loads and stores share one in-order counter)
+template <int D>
+struct ResetRow {
+  float dof0[D];
+  float ip[3];
+  float4 iq;
+};
+
+template <int D>
+__device__ __forceinline__ ResetRow<D> reset_load(const oige_locomotion_reset_io& r, int64_t i) {
+  ResetRow<D> w;
+#pragma unroll
+  for (int j = 0; j < D; ++j) w.dof0[j] = r.initial_dof_pos[i * D + j];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) w.ip[j] = r.initial_root_pos[i * 3 + j];
+  w.iq = *reinterpret_cast<const float4*>(r.initial_root_rot + i * 4);
+  return w;
+}
+
 template <int D, bool STAGE = false>
 __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const oige_locomotion_buffers& b,
-                                          const oige_locomotion_reset_io& r, int64_t i, int64_t k,
+                                          const oige_locomotion_reset_io& r, const ResetRow<D>& w, int64_t i, int64_t k,
                                           float* __restrict__ stage_pos = nullptr, float* __restrict__ qv_out = nullptr) {
   // the 2*D uniform draws: [0,D) -> dof_pos (1st torch.rand, :137), [D,2D) -> dof_vel (2nd, :139)
   float u[2 * D];
@@ -343,7 +363,7 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
   for (int j = 0; j < D; ++j) {
     // torch_rand_float(lo, hi): (hi - lo) * u + lo, with hi - lo folded in double first (:137,:139)
     const float dp = 0.4f * u[j] + (-0.2f);
-    qp[j] = tensor_clamp(r.initial_dof_pos[i * D + j] + dp, p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :138
+    qp[j] = tensor_clamp(w.dof0[j] + dp, p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :138
     qv[j] = 0.2f * u[D + j] + (-0.1f);
   }
   if (STAGE) {
@@ -365,8 +385,8 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
       r.dof_vel_out[k * D + j] = qv[j];
     }
   }
-  const float* ip = r.initial_root_pos + i * 3;
-  const float4 iq = *reinterpret_cast<const float4*>(r.initial_root_rot + i * 4);
+  const float* ip = w.ip;
+  const float4 iq = w.iq;
   r.root_pos_out[k * 3 + 0] = ip[0];
   r.root_pos_out[k * 3 + 1] = ip[1];
   r.root_pos_out[k * 3 + 2] = ip[2];
@@ -391,70 +411,85 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
   const int64_t G = num_groups(a.n);
   const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
 
+  // Order: every load of the workgroup first (the reset flag, the group's offsets, the action quads, and - after the flagged
+  // envs are ranked - the reset rows), then every store: a load issued behind a store waits for that store's round trip.
+  const bool flagged = env < a.n && a.b.reset_buf[env] != 0;
+  const int32_t k0 = group_offsets[g];
+  const int cnt = group_offsets[g + 1] - k0;
+
   // forces = actions * joint_gears * power_scale (:125-126), lane-linear over the group's
   // contiguous 256*D floats; optional clamp (vec_env_rlgames.py:77) and clone (:125)
-  {
-    const int64_t base = g * GROUP * D;
-    const int64_t total = a.n * D;
-    constexpr int NF4 = GROUP * D / 4;
+  const int64_t base = g * GROUP * D;
+  const int64_t total = a.n * D;
+  constexpr int NF4 = GROUP * D / 4;
+  constexpr int ITS = (NF4 + GROUP - 1) / GROUP;
+  float v[ITS][4];
 #pragma unroll
-    for (int it = 0; it < (NF4 + GROUP - 1) / GROUP; ++it) {
-      const int f = it * GROUP + threadIdx.x;
-      if (f >= NF4) break;
-      const int64_t e = base + 4 * (int64_t)f;
-      if (e >= total) break;
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      const bool whole = e + 3 < total;
-      if (whole) {
+  for (int it = 0; it < ITS; ++it) {
+    const int f = it * GROUP + threadIdx.x;
+    const int64_t e = base + 4 * (int64_t)f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[it][k] = 0.f;
+    if (f < NF4 && e < total) {
+      if (e + 3 < total) {
         const float4 t = *reinterpret_cast<const float4*>(a.actions_in + e);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        v[it][0] = t.x; v[it][1] = t.y; v[it][2] = t.z; v[it][3] = t.w;
       } else {
         for (int k = 0; k < 4; ++k)
-          if (e + k < total) v[k] = a.actions_in[e + k];
-      }
-      float fo[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (a.flags & OIGE_PRE_CLAMP_ACTIONS) v[k] = clamp_sym(v[k], a.p.clip_actions);
-        const int col = (4 * f + k) % D;  // the group's run starts at a multiple of D
-        fo[k] = (v[k] * a.p.joint_gears[col]) * a.p.power_scale;
-      }
-      if (whole) {
-        if (a.actions_out) *reinterpret_cast<float4*>(a.actions_out + e) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(a.forces_out + e) = make_float4(fo[0], fo[1], fo[2], fo[3]);
-      } else {
-        for (int k = 0; k < 4; ++k)
-          if (e + k < total) {
-            if (a.actions_out) a.actions_out[e + k] = v[k];
-            a.forces_out[e + k] = fo[k];
-          }
+          if (e + k < total) v[it][k] = a.actions_in[e + k];
       }
     }
   }
 
-  // compaction rank + reset of the flagged envs (:121-123).  The flagged envs of the group are first packed
+  // compaction rank of the flagged envs (:121-123).  The flagged envs of the group are first packed
   // into LDS so that the reset runs on DENSE lanes (thread j takes the group's j-th flagged env): with a few
   // flagged lanes per wave the divergent version spent 4 waves' worth of issue slots on ~10 % of the lanes, and
   // consecutive lanes now write consecutive compacted rows.
-  const bool flagged = env < a.n && a.b.reset_buf[env] != 0;
   const int64_t k = group_rank(flagged, group_offsets, g, lds4);
-  const int32_t k0 = group_offsets[g];
-  const int cnt = group_offsets[g + 1] - k0;
   if (flagged) s_list[(int)(k - k0)] = (int)threadIdx.x;
   __syncthreads();
+  const bool mine = (int)threadIdx.x < cnt;
+  const int64_t my_env = g * GROUP + (mine ? s_list[threadIdx.x] : 0);
+  ResetRow<D> row;
+  if (mine) row = reset_load<D>(a.r, my_env);
+
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    const int f = it * GROUP + threadIdx.x;
+    const int64_t e = base + 4 * (int64_t)f;
+    if (f >= NF4 || e >= total) break;
+    float fo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (a.flags & OIGE_PRE_CLAMP_ACTIONS) v[it][k] = clamp_sym(v[it][k], a.p.clip_actions);
+      const int col = (4 * f + k) % D;  // the group's run starts at a multiple of D
+      fo[k] = (v[it][k] * a.p.joint_gears[col]) * a.p.power_scale;
+    }
+    if (e + 3 < total) {
+      if (a.actions_out) *reinterpret_cast<float4*>(a.actions_out + e) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
+      *reinterpret_cast<float4*>(a.forces_out + e) = make_float4(fo[0], fo[1], fo[2], fo[3]);
+    } else {
+      for (int k = 0; k < 4; ++k)
+        if (e + k < total) {
+          if (a.actions_out) a.actions_out[e + k] = v[it][k];
+          a.forces_out[e + k] = fo[k];
+        }
+    }
+  }
+
+  // reset of the flagged envs.
   // Rows that are not a whole number of float4 (Humanoid: 21 floats) would leave each lane walking its own 84-byte row with
   // scalar stores; the group's compacted rows are ONE contiguous run of cnt * D floats, so they are staged through LDS and
   // written lane-linearly, dof_pos then dof_vel through the same buffer (Ant's 32-byte rows are two float4 per lane, already
   // contiguous across lanes).
   constexpr bool STAGE = (D % 4) != 0;
   __shared__ float s_rows[STAGE ? GROUP * D : 1];
-  const bool mine = (int)threadIdx.x < cnt;
   if (!STAGE) {
-    if (mine) reset_env<D>(a.p, a.b, a.r, g * GROUP + s_list[threadIdx.x], (int64_t)k0 + threadIdx.x);
+    if (mine) reset_env<D>(a.p, a.b, a.r, row, my_env, (int64_t)k0 + threadIdx.x);
   } else if (cnt > 0) {  // cnt is uniform over the workgroup: the barriers below are reached by all of it or none
     float qv[D];
     if (mine)
-      reset_env<D, true>(a.p, a.b, a.r, g * GROUP + s_list[threadIdx.x], (int64_t)k0 + threadIdx.x, s_rows + threadIdx.x * D, qv);
+      reset_env<D, true>(a.p, a.b, a.r, row, my_env, (int64_t)k0 + threadIdx.x, s_rows + threadIdx.x * D, qv);
     __syncthreads();
     const int run = cnt * D;
     float* dst = a.r.dof_pos_out + (int64_t)k0 * D;
@@ -477,7 +512,7 @@ __global__ __launch_bounds__(256) void locomotion_reset_idx_kernel(const LocoPre
   if (k >= max_ids || k >= *a.r.count) return;
   const int64_t i = a.r.env_ids[k];
   if (i < 0 || i >= a.n) return;
-  reset_env<D>(a.p, a.b, a.r, i, k);
+  reset_env<D>(a.p, a.b, a.r, reset_load<D>(a.r, i), i, k);
 }
 
 // ---------------------------------------------------------------- host dispatch

@@ -13,4 +13,4 @@ for r in rows[:9]:
     if "oige::" in r["Name"]:
         print(f'{r["Name"][:70]:70s} calls {r["Calls"]:>4s} avg {float(r["AverageNs"])/1e3:8.1f} us')
 PY
-tail -1 /tmp/kt_$T.log | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('step_ms', round(d['ms_per_step'],4), 'post_ms', round(d['roofline']['avg_kernel_ms'],4), 'pre_ms', round(d['roofline']['pre_physics_ms'],4), 'frac', round(d['roofline']['frac'],4))"
+grep '^{"metric' /tmp/kt_$T.log | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('step_ms', round(d['ms_per_step'],4), 'post_ms', round(d['roofline']['avg_kernel_ms'],4), 'pre_ms', round(d['roofline']['pre_physics_ms'],4), 'frac', round(d['roofline']['frac'],4))"
