@@ -201,19 +201,24 @@ __device__ __forceinline__ void st4_plain(float* p, const float4 v) { *reinterpr
 #endif
 
 // uniform noise of four consecutive observation columns starting at flat float offset `off` (:438-439)
-__device__ __forceinline__ void anymal_noise4(const oige_anymal_reset_io& r, uint64_t step, int64_t off, float (&uu)[4]) {
-  if (r.noise_u) {
-    const float4 t4 = *reinterpret_cast<const float4*>(r.noise_u + off);
+// NOISE_IN: the uniforms come from the caller's tensor (the parity tests' replay path).  A compile-time split: as a
+// run-time test the load sat in a conditional block and its join waited for EVERY memory operation in flight, the
+// previous pass's observation stores included -- one HBM round trip per float4 of noise, whichever way the test went.
+// `gf` = off / 4, the flat float4 index in obs_buf: below 2^31 for every accepted num_envs (< 2^23 envs x 47 float4), so the
+// counter's second word is the stream tag alone and the index arithmetic stays 32-bit (64-bit multiplies are quarter rate)
+template <bool NOISE_IN>
+__device__ __forceinline__ void anymal_noise4(const oige_anymal_reset_io& r, uint64_t step, uint32_t gf, float (&uu)[4]) {
+  if (NOISE_IN) {
+    const float4 t4 = *reinterpret_cast<const float4*>(r.noise_u + 4 * (int64_t)gf);
     uu[0] = t4.x; uu[1] = t4.y; uu[2] = t4.z; uu[3] = t4.w;
   } else {
-    const int64_t gf = off / 4;
-    const u4 cc{(uint32_t)gf, (uint32_t)(gf >> 32) | (3u << 16), (uint32_t)step, (uint32_t)(step >> 32)};
+    const u4 cc{gf, 3u << 16, (uint32_t)step, (uint32_t)(step >> 32)};
     const u4 x = philox4x32_10(cc, (uint32_t)r.seed, (uint32_t)(r.seed >> 32));
     uu[0] = u01(x.x); uu[1] = u01(x.y); uu[2] = u01(x.z); uu[3] = u01(x.w);
   }
 }
 
-template <bool FULLTILE>
+template <bool FULLTILE, bool NOISE_IN>
 __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __restrict__ lds, int64_t t, int nv) {
   float* rows = lds;                         // 64 x 52
   float* s_ns = lds + TILE * ARW;            // noise_scale_vec (:157-171) of observation columns 0:36 (48 slots kept)
@@ -525,11 +530,12 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
       if (!FULLTILE && e >= nv) continue;
       const int col = 4 * j;  // LDS column == observation column
       float4 v = lds4(rows + e * ARW + col);
-      const int64_t off = (env0 + e) * AO + col;
+      const uint32_t gf = __umul24((uint32_t)env0 + (uint32_t)e, (uint32_t)(AO / 4)) + (uint32_t)j;  // env < 2^23
+      const int64_t off = 4 * (int64_t)gf;  // (env0 + e) * AO + col
 #ifndef OIGE_EXP_NO_NOISE
       if (p.add_noise) {
         float uu[4];
-        anymal_noise4(a.r, noise_step, off, uu);
+        anymal_noise4<NOISE_IN>(a.r, noise_step, gf, uu);
         const float4 sc = lds4(s_ns + col);
         v.x = v.x + (2.0f * uu[0] - 1.0f) * sc.x;
         v.y = v.y + (2.0f * uu[1] - 1.0f) * sc.y;
@@ -553,10 +559,14 @@ __global__ __launch_bounds__(WAVE) void anymal_head_kernel(const AnymalPost a) {
   __shared__ __align__(16) float lds[TILE * ARW + 48];  // rows + noise scales by column
   const int64_t t = blockIdx.x;
   const int64_t left = a.n - t * TILE;
-  if (left >= TILE)
-    anymal_head_tile<true>(a, lds, t, TILE);
-  else
-    anymal_head_tile<false>(a, lds, t, (int)left);
+  const bool noise_in = a.r.noise_u != nullptr;
+  if (left >= TILE) {
+    if (noise_in) anymal_head_tile<true, true>(a, lds, t, TILE);
+    else anymal_head_tile<true, false>(a, lds, t, TILE);
+  } else {
+    if (noise_in) anymal_head_tile<false, true>(a, lds, t, (int)left);
+    else anymal_head_tile<false, false>(a, lds, t, (int)left);
+  }
 }
 
 // ------------------------------------------------------------------ height scan (:582-604, :537-539)
@@ -587,13 +597,22 @@ __device__ __forceinline__ v2f div_by_const2(v2f x, float h, float inv) {
   return __builtin_elementwise_fma(__builtin_elementwise_fma(-q1, hh, x), ii, q1);
 }
 
+// max(min(i, hi), 0) for hi >= 0 as the one median instruction (the compiler keeps two: it cannot see that hi >= 0)
+__device__ __forceinline__ int clip_index(int i, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(i), "s"(hi));
+  return r;
+}
+
 __device__ __forceinline__ void cursor_advance(int& e, int& k, int de, int dk, int period) {
   e += de;
   k += dk;
   if (k >= period) { k -= period; e += 1; }
 }
 
-template <bool FULLTILE>
+// HMIN: the tabulated min is there (a compile-time split: as a run-time test inside the loop every gather sat in its own
+// conditional block followed by a full wait, one exposed round trip per pass)
+template <bool FULLTILE, bool HMIN, bool NOISE_IN>
 __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __restrict__ s_env, float* __restrict__ s_k,
                                                  float* __restrict__ s_strip, int64_t t, int nv) {
   const oige_anymal_params& p = a.p;
@@ -636,7 +655,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
   const float hscale = p.horizontal_scale, hinv = 1.0f / p.horizontal_scale;
   const float nscale = p.noise_scales[5];
   const v2f border = {p.border_size, p.border_size};
-  const char* hmin = reinterpret_cast<const char*>(a.s.height_min);  // uniform: NULL -> the reference's two gathers
+  const char* hmin = reinterpret_cast<const char*>(a.s.height_min);  // NULL (HMIN false) -> the reference's two gathers
   const int wave = tid >> 6, lane = tid & (WAVE - 1);
   constexpr int NW = ANT / WAVE;
   float* strip = s_strip + wave * 256;
@@ -649,6 +668,10 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
   for (int c = wave; c < CHUNKS; c += NW) {
     int idx[ANG];
     float pz[ANG];
+    // The four passes advance STAGE BY STAGE (every pass's table reads, then every pass's first sum, ...): a packed fp32
+    // operation needs a free issue slot before a dependent one, and written pass by pass each of the nine in a pass's
+    // chain was followed by an idle slot.
+    v2f hxy[ANG], t1[ANG], t2[ANG], bxy[ANG];
 #pragma unroll
     for (int g = 0; g < ANG; ++g) {
       const float4 kk = lds4(s_k + 4 * pk);  // hx, hy, AB offset, CD offset
@@ -657,19 +680,40 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
       const float2 cd = *reinterpret_cast<const float2*>(eb + __float_as_int(kk.w));
       const float4 pp = *reinterpret_cast<const float4*>(eb + 4 * AE_POS);  // base x, y, z - 0.5
       // both components per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operation on each half)
-      const v2f hxy = {kk.x, kk.y}, t1 = {ab.x, cd.y}, t2 = {-cd.x, ab.y}, bxy = {pp.x, pp.y};
-      const v2f rxy = (hxy + t1) + t2;  // rx = (hx + w tx) + (-(z ty)), ry = (hy + w ty) + (z tx)
-      const v2f w = div_by_const2((rxy + bxy) + border, hscale, hinv);  // :586-593
-      // .long() truncates toward zero; v_cvt_i32_f32 does too and saturates, and the clip that follows (:596-597) maps
-      // every saturated value where int64 truncation + clip would (out-of-range low -> 0, high -> rows - 2)
-      int px = (int)w.x, py = (int)w.y;
-      px = max(min(px, max_r), 0);
-      py = max(min(py, max_c), 0);
-      idx[g] = __mul24(px, hs_cols) + py;  // both below 2^24: v_mad_i32_i24 is full rate, v_mul_lo_u32 quarter rate
+      hxy[g] = v2f{kk.x, kk.y}; t1[g] = v2f{ab.x, cd.y}; t2[g] = v2f{-cd.x, ab.y}; bxy[g] = v2f{pp.x, pp.y};
       pz[g] = pp.z;
       // next pass: +64 points; after the last pass, the first pass of the wave's next chunk: +4*256 - 192 = 5*140 + 132
       if (g != ANG - 1) cursor_advance(pe, pk, 0, 64, AP);
       else cursor_advance(pe, pk, 5, 132, AP);
+    }
+    v2f x[ANG], q[ANG], r[ANG];
+    const v2f hh = {hscale, hscale}, ii = {hinv, hinv};
+    // rx = (hx + w tx) + (-(z ty)), ry = (hy + w ty) + (z tx); then ((r + base) + border) / horizontal_scale (:586-593)
+    // as div_by_const2's five operations
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) x[g] = hxy[g] + t1[g];
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) x[g] = x[g] + t2[g];
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) x[g] = x[g] + bxy[g];
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) x[g] = x[g] + border;
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) q[g] = x[g] * ii;
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) r[g] = __builtin_elementwise_fma(-q[g], hh, x[g]);
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) q[g] = __builtin_elementwise_fma(r[g], ii, q[g]);
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) r[g] = __builtin_elementwise_fma(-q[g], hh, x[g]);
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) q[g] = __builtin_elementwise_fma(r[g], ii, q[g]);
+#pragma unroll
+    for (int g = 0; g < ANG; ++g) {
+      // .long() truncates toward zero; v_cvt_i32_f32 does too and saturates, and the clip that follows (:596-597) maps
+      // every saturated value where int64 truncation + clip would (out-of-range low -> 0, high -> rows - 2)
+      const int px = clip_index((int)q[g].x, max_r), py = clip_index((int)q[g].y, max_c);
+      idx[g] = __mul24(px, hs_cols) + py;  // both below 2^24: v_mad_i32_i24 is full rate, v_mul_lo_u32 quarter rate
     }
     int16_t h1[ANG], h2[ANG];
 #pragma unroll
@@ -681,7 +725,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
       // unsigned 32-bit element offsets: the gathers take the table's base from scalar registers and the offset as it
       // is (no sign extension, no 64-bit address arithmetic per lane)
       const uint32_t o1 = 2u * (uint32_t)idx[g], o2 = o1 + 2u * (uint32_t)(hs_cols + 1);  // byte offsets (the map is < 2 GiB)
-      if (hmin) {  // min(h[px, py], h[px + 1, py + 1]) tabulated per map: one gather (oige_anymal_height_min)
+      if (HMIN) {  // min(h[px, py], h[px + 1, py + 1]) tabulated per map: one gather (oige_anymal_height_min)
         h1[g] = h2[g] = *reinterpret_cast<const int16_t*>(hmin + o1);
       } else {
         const char* hb = reinterpret_cast<const char*>(a.s.height_samples);
@@ -702,12 +746,14 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
       float4 v = lds4(strip + 4 * lane);
-      const int64_t off = (env0 + fe) * AO + 36 + 4 * fk;
+      static_assert(AO % 4 == 0, "whole float4 per observation row");
+      const uint32_t gf = __umul24((uint32_t)env0 + (uint32_t)fe, (uint32_t)(AO / 4)) + 9u + (uint32_t)fk;  // env < 2^23
+      const int64_t off = 4 * (int64_t)gf;  // (env0 + fe) * AO + 36 + 4 * fk
       if (FULLTILE || fe < nv) {
 #ifndef OIGE_EXP_NO_NOISE
         if (p.add_noise) {
           float uu[4];
-          anymal_noise4(a.r, noise_step, off, uu);
+          anymal_noise4<NOISE_IN>(a.r, noise_step, gf, uu);
           v.x = v.x + (2.0f * uu[0] - 1.0f) * nscale;
           v.y = v.y + (2.0f * uu[1] - 1.0f) * nscale;
           v.z = v.z + (2.0f * uu[2] - 1.0f) * nscale;
@@ -772,10 +818,14 @@ __global__ __launch_bounds__(ANT) void anymal_scan_kernel(const AnymalPost a) {
   }
   const int64_t t = (int64_t)blockIdx.x - 1;
   const int64_t left = a.n - t * TILE;
-  if (left >= TILE)
-    anymal_scan_tile<true>(a, s_env, s_k, s_strip, t, TILE);
-  else
-    anymal_scan_tile<false>(a, s_env, s_k, s_strip, t, (int)left);
+  // the product path (tabulated min, Philox noise, whole tile) is one specialisation; the others share slower generic ones
+  const bool hmin = a.s.height_min != nullptr, noise_in = a.r.noise_u != nullptr;
+  const int nv = left >= TILE ? TILE : (int)left;
+  if (left >= TILE && hmin && !noise_in) anymal_scan_tile<true, true, false>(a, s_env, s_k, s_strip, t, TILE);
+  else if (hmin && !noise_in) anymal_scan_tile<false, true, false>(a, s_env, s_k, s_strip, t, nv);
+  else if (hmin) anymal_scan_tile<false, true, true>(a, s_env, s_k, s_strip, t, nv);
+  else if (!noise_in) anymal_scan_tile<false, false, false>(a, s_env, s_k, s_strip, t, nv);
+  else anymal_scan_tile<false, false, true>(a, s_env, s_k, s_strip, t, nv);
 }
 
 // stand-alone extras for reset_idx(env_ids) (no scan there)

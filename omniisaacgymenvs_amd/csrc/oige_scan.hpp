@@ -23,8 +23,14 @@ __device__ __forceinline__ void scan_groups_body(const int32_t* __restrict__ til
   const int64_t g0 = (int64_t)tid * per;
   const int64_t g1 = g0 + per < n_groups ? g0 + per : n_groups;
   const int4* c4 = reinterpret_cast<const int4*>(tile_counts);  // GROUP_TILES == 4 counts per group
-  int mine = 0;
-  for (int64_t g = g0; g < g1; ++g) mine += group_count(c4, g, n_tiles);
+  // the first KEEP groups of the run are fetched together (independent loads, one latency) and kept in registers for the
+  // second pass; up to 4096 groups (1 M envs) that is the whole run
+  constexpr int KEEP = 4;
+  int first[KEEP];
+#pragma unroll
+  for (int j = 0; j < KEEP; ++j) first[j] = g0 + j < g1 ? group_count(c4, g0 + j, n_tiles) : 0;
+  int mine = (first[0] + first[1]) + (first[2] + first[3]);
+  for (int64_t g = g0 + KEEP; g < g1; ++g) mine += group_count(c4, g, n_tiles);
   // inclusive scan of `mine` across the wave, then across waves
   int incl = mine;
 #pragma unroll
@@ -38,7 +44,12 @@ __device__ __forceinline__ void scan_groups_body(const int32_t* __restrict__ til
   int base = 0;
   for (int i = 0; i < w; ++i) base += wave_tot[i];
   int run = base + incl - mine;  // exclusive prefix at g0
-  for (int64_t g = g0; g < g1; ++g) {
+#pragma unroll
+  for (int j = 0; j < KEEP; ++j) {
+    if (g0 + j < g1) group_offsets[g0 + j] = run;
+    run += first[j];
+  }
+  for (int64_t g = g0 + KEEP; g < g1; ++g) {
     group_offsets[g] = run;
     run += group_count(c4, g, n_tiles);
   }
