@@ -767,7 +767,24 @@ __device__ __forceinline__ q4 randomize_rotation(float rand0, float rand1) {
   return quat_mul(quat_from_angle_unit_axis<0>(rand0 * OIGE_PI_F), quat_from_angle_unit_axis<1>(rand1 * OIGE_PI_F));
 }
 
-// reset_target_pose (:377-395) for env i -> compacted row k of (pos_out, rot_out)
+// reset_target_pose (:377-395) for env i -> compacted row k of (pos_out, rot_out), from rows the caller fetched
+// (gi = goal_init_pos[i], ep = env_pos[i]) and the two rotation draws.  state_rot = false leaves goal_rot[i] alone: a
+// goal-only reset of an env that reset_idx also resets this step (its nested reset_target_pose comes second in the
+// reference, :324-329, and wins; goal_pos and reset_goal_buf get the same value from both)
+__device__ __forceinline__ void hand_goal_write(const HandPre& a, int64_t i, int64_t k, float u0, float u1, const float (&gi)[3],
+                                                const float (&ep)[3], bool state_rot, float* pos_out, float* rot_out) {
+  const q4 nr = randomize_rotation(u0, u1);
+  a.b.goal_pos[i * 3 + 0] = gi[0];
+  a.b.goal_pos[i * 3 + 1] = gi[1];
+  a.b.goal_pos[i * 3 + 2] = gi[2];
+  if (state_rot) *reinterpret_cast<float4*>(a.b.goal_rot + i * 4) = make_float4(nr.w, nr.x, nr.y, nr.z);
+  pos_out[k * 3 + 0] = (gi[0] + a.p.goal_displacement[0]) + ep[0];
+  pos_out[k * 3 + 1] = (gi[1] + a.p.goal_displacement[1]) + ep[1];
+  pos_out[k * 3 + 2] = (gi[2] + a.p.goal_displacement[2]) + ep[2];
+  *reinterpret_cast<float4*>(rot_out + k * 4) = make_float4(nr.w, nr.x, nr.y, nr.z);
+  a.b.reset_goal_buf[i] = 0;
+}
+
 __device__ __forceinline__ void hand_reset_goal(const HandPre& a, int64_t i, int64_t k, const float* u4row,
                                                 uint32_t stream, float* pos_out, float* rot_out) {
   float u[4];
@@ -777,19 +794,10 @@ __device__ __forceinline__ void hand_reset_goal(const HandPre& a, int64_t i, int
   } else {
     hand_draw<4>(a.r, i, stream, u);
   }
-  const q4 nr = randomize_rotation(u[0], u[1]);
-  const float* gi = a.r.goal_init_pos + i * 3;
-  const float* ep = a.r.env_pos + i * 3;
-  const float gx = gi[0], gy = gi[1], gz = gi[2];
-  a.b.goal_pos[i * 3 + 0] = gx;
-  a.b.goal_pos[i * 3 + 1] = gy;
-  a.b.goal_pos[i * 3 + 2] = gz;
-  *reinterpret_cast<float4*>(a.b.goal_rot + i * 4) = make_float4(nr.w, nr.x, nr.y, nr.z);
-  pos_out[k * 3 + 0] = (gx + a.p.goal_displacement[0]) + ep[0];
-  pos_out[k * 3 + 1] = (gy + a.p.goal_displacement[1]) + ep[1];
-  pos_out[k * 3 + 2] = (gz + a.p.goal_displacement[2]) + ep[2];
-  *reinterpret_cast<float4*>(rot_out + k * 4) = make_float4(nr.w, nr.x, nr.y, nr.z);
-  a.b.reset_goal_buf[i] = 0;
+  const float* gp = a.r.goal_init_pos + i * 3;
+  const float* epp = a.r.env_pos + i * 3;
+  const float gi[3] = {gp[0], gp[1], gp[2]}, ep[3] = {epp[0], epp[1], epp[2]};
+  hand_goal_write(a, i, k, u[0], u[1], gi, ep, true, pos_out, rot_out);
 }
 
 // reset_idx (:397-441) for env i -> compacted row k
@@ -830,27 +838,6 @@ __device__ __forceinline__ void hand_reset_env(const HandPre& a, int64_t i, int6
   a.r.env_ids[k] = i;
 }
 
-// reset_idx (:397-441) WITHOUT its (.,24) DOF rows: goal re-draw, object pose rows, flags.  The DOF rows and
-// the prev/cur targets of a reset env are produced by the elementwise pass of hand_pre_kernel.
-__device__ __forceinline__ void hand_reset_env_head(const HandPre& a, int64_t i, int64_t k) {
-  const oige_hand_params& p = a.p;
-  float u[8];
-  hand_draw<8>(a.r, i, 1u, u);                                                                     // draws 0..4 of the (n,53) table
-  hand_reset_goal(a, i, k, nullptr, 2u, a.r.r_goal_world_pos_out, a.r.r_goal_rot_out);             // :401
-  const float* oi = a.r.object_init_pos + i * 3;
-  const float* ep = a.r.env_pos + i * 3;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) a.r.object_pos_out[k * 3 + c] = (oi[c] + p.reset_position_noise * u[c]) + ep[c];  // :404-406
-  const q4 orot = randomize_rotation(u[3], u[4]);                                                       // :408-410
-  *reinterpret_cast<float4*>(a.r.object_rot_out + k * 4) = make_float4(orot.w, orot.x, orot.y, orot.z);
-#pragma unroll
-  for (int c = 0; c < 6; ++c) a.r.object_vel_out[k * 6 + c] = 0.0f;  // :412-413
-  a.b.progress_buf[i] = 0;  // :439-441
-  a.b.reset_buf[i] = 0;
-  a.b.successes[i] = 0.0f;
-  a.r.env_ids[k] = i;
-}
-
 // draws idx0 .. idx0+3 of env i's U(-1,1) table on `stream`, idx0 = 4m + 1: words 1..3 of block m, word 0 of block m+1
 __device__ __forceinline__ void hand_draw4_at(const oige_hand_reset_io& r, int64_t i, uint32_t stream, int idx0, float (&out)[4]) {
   const uint32_t m = (uint32_t)(idx0 >> 2);
@@ -861,23 +848,67 @@ __device__ __forceinline__ void hand_draw4_at(const oige_hand_reset_io& r, int64
   out[0] = um11(x0.y); out[1] = um11(x0.z); out[2] = um11(x0.w); out[3] = um11(x1.x);
 }
 
-// pre_physics_step (:314-362) for one group of 256 envs, in four phases:
-//   1. compaction ranks of reset_goal_buf / reset_buf; the group's actions (one contiguous 256x20 run) are read
-//      lane-linear, clamped, cloned to actions_out and staged in LDS;
-//   2. the flagged envs run reset_target_pose / reset_idx on DENSE lanes (thread j = j-th flagged env of the group);
-//   3. one lane-linear pass over the group's contiguous 256x24 prev/cur target rows: reset rows take their
-//      re-drawn DOF positions (also written as compacted dof_pos_out / dof_vel_out rows), then every actuated
-//      element gets scale -> EMA -> clamp (or the relative-control update); results land in the LDS action tile;
-//   4. the LDS tile streams out as targets_out.
-// Every global access of phases 1, 3 and 4 is a 16-byte lane-linear one (the first version wrote prev/cur/targets with
-// per-env strided dword stores: 4x the algorithmic write traffic, 460 us at 1 M envs).
-template <int D, int A>
-__global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
+// per-DOF rows of the params, copied to LDS by the kernels that index them by a run-time column: indexed in place
+// (the kernel-argument block) such an access is a VECTOR load, and behind a store it waits for that store's round trip
+struct HandDofTab {
+  const float* lower;
+  const float* upper;
+  const float* def_pos;
+  const float* def_vel;
+};
+
+// the re-drawn DOF state of reset env i, columns j0 .. j0+3 (:415-432): pos (= the new prev and cur targets) and vel
+__device__ __forceinline__ void hand_redraw_quad(const HandPre& a, const HandDofTab& t, int64_t i, int D, int j0, float (&pos)[4],
+                                                 float (&vel)[4]) {
+  const oige_hand_params& p = a.p;
+  float up[4], uv[4] = {0.f, 0.f, 0.f, 0.f};
+  hand_draw4_at(a.r, i, 1u, 5 + j0, up);
+  if (p.reset_dof_vel_noise != 0.0f) hand_draw4_at(a.r, i, 1u, 5 + D + j0, uv);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int j = j0 + q;
+    const float delta_max = t.upper[j] - t.def_pos[j];
+    const float delta_min = t.lower[j] - t.def_pos[j];
+    const float rand_delta = delta_min + ((delta_max - delta_min) * 0.5f) * (up[q] + 1.0f);  // :419
+    pos[q] = t.def_pos[j] + p.reset_dof_pos_noise * rand_delta;                               // :421
+    vel[q] = t.def_vel[j] + p.reset_dof_vel_noise * uv[q];                                    // :426-429
+  }
+}
+
+// reset envs of a group whose re-drawn rows go through LDS (computed on dense lanes); a group with more (the first step
+// after a full reset) handles the rest per lane inside the elementwise passes
+constexpr int HAND_RMAX = 64;
+#ifndef OIGE_HAND_PRE_WAVES
+#define OIGE_HAND_PRE_WAVES 4
+#endif
+
+// pre_physics_step (:314-362) for one group of 256 envs.  Order: EVERY load first, then every store -- loads and stores
+// share one in-order counter, so a load issued behind a store waits for that store's round trip to HBM, and a load
+// inside a conditional block makes its join wait for everything in flight (the first version ran load -> store ->
+// load ... eleven times per thread, each step a full round trip: 3.6 TB/s).
+//   0. issue the group's lane-linear loads: actions (256x20 contiguous floats), their correlated noise, prev / cur
+//      targets (256x24); flags, noise counters, compaction offsets;
+//   1. compaction ranks of reset_goal_buf / reset_buf, the flagged envs packed into LDS lists;
+//   2. the flagged envs run reset_target_pose / reset_idx (without its DOF rows) on DENSE lanes -- reset envs on the
+//      first lanes of the group, goal-only envs from lane 64 on, so the two run side by side on different SIMDs -- and
+//      the DOF rows / correlated action noise of the reset envs are re-drawn on dense lanes too (one float4 per lane:
+//      as a per-lane branch of the elementwise passes every wave holding one reset env ran the Philox draws for all
+//      64 lanes, six times over), written as compacted dof_pos_out / dof_vel_out rows and staged in LDS;
+//   3. actions: noise -> clamp -> actions_out, LDS tile;
+//   4. prev/cur targets: reset rows take their staged DOF positions, then every actuated element gets
+//      scale -> EMA -> clamp (or the relative-control update); results land in the LDS action tile;
+//   5. the LDS tile streams out as targets_out.
+template <int D, int A, bool DR>
+__global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND_PRE_WAVES, OIGE_HAND_PRE_WAVES))) void hand_pre_kernel(const HandPre a) {
   __shared__ int lds_a[GROUP_TILES], lds_b[GROUP_TILES];
   __shared__ int s_list_r[GROUP], s_list_g[GROUP], s_rank[GROUP];
   __shared__ int s_inv[D];
-  __shared__ int s_dec[GROUP];
+  __shared__ int s_dec[DR ? GROUP : 1];
   __shared__ __align__(16) float s_act[GROUP * A];
+  __shared__ __align__(16) float s_rpos[HAND_RMAX * D], s_rvel[HAND_RMAX * D];
+  __shared__ __align__(16) float s_rcor[DR ? HAND_RMAX * A : 4];
+  __shared__ __align__(16) float s_tab[4 * D];
+  const HandDofTab tab{s_tab, s_tab + D, s_tab + 2 * D, s_tab + 3 * D};
   const oige_hand_params& p = a.p;
   const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
@@ -886,150 +917,244 @@ __global__ __launch_bounds__(GROUP) void hand_pre_kernel(const HandPre a) {
   const int32_t* off_r = a.b.reset_workspace + G * GROUP_TILES;
   const int32_t* off_g = a.b.goal_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
-  const bool f_env = live && a.b.reset_buf[env] != 0;
-  const bool f_goal = live && a.b.reset_goal_buf[env] != 0;
-  if (tid < D) s_inv[tid] = -1;
-  if (a.dr) {  // the wrapper hands the noise the reset_buf as it stands before this step's resets (vec_env_rlgames.py:72-75)
-    const NoiseDecision d = noise_decide_flag(a.dn, env, live, f_env);
-    if (live) a.dn.counter[env] = d.cnt;
+  const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
+  const int64_t base_a = g * GROUP * A, base_d = g * GROUP * D;
+  const int nf4a = (int)(envs_here * A / 4), nf4d = (int)(envs_here * D / 4);  // A % 4 == 0, D % 4 == 0
+  static_assert(A % 4 == 0 && D % 4 == 0 && D <= 32, "whole float4 per row; the actuated set is a 32-bit mask");
+  const bool has_cor = DR && a.dn.on_reset.enabled != 0;
+
+  // ---- 0: loads.  None is conditional: a lane past the group's end re-reads the group's first float4, a quad that does
+  // not need its cur_targets (all four DOFs actuated) re-reads its prev_targets quad, a missing correlated-noise buffer
+  // reads the actions again (same lines, already on their way: no HBM traffic)
+  const int64_t f_env_raw = live ? a.b.reset_buf[env] : 0;
+  const int64_t f_goal_raw = live ? a.b.reset_goal_buf[env] : 0;
+  int cnt_in = 0;
+  if (DR) cnt_in = a.dn.counter[live ? env : 0];
+  uint32_t amask = 0;  // uniform: bit j set = DOF j actuated
+#pragma unroll
+  for (int t = 0; t < A; ++t) amask |= 1u << p.actuated_dof_indices[t];
+  float4 act[A / 4], cor[DR ? A / 4 : 1], prv[D / 4], cur[D / 4];
+  {
+    const float* cor_src = has_cor ? a.dn.correlated_noise : a.actions_in;
+#pragma unroll
+    for (int it = 0; it < A / 4; ++it) {
+      const int f = it * GROUP + tid;
+      const int fa = f < nf4a ? f : 0;
+      act[it] = LD4S(a.actions_in + base_a + 4 * fa);
+      if (DR) cor[it] = LD4S(cor_src + base_a + 4 * fa);
+    }
+#pragma unroll
+    for (int it = 0; it < D / 4; ++it) {
+      const int f = it * GROUP + tid;
+      const int fd = f < nf4d ? f : 0;
+      const int e = 4 * fd;
+      const int j0 = e % D;
+      const bool all_act = ((amask >> j0) & 0xFu) == 0xFu;
+      prv[it] = LD4S(a.b.prev_targets + base_d + e);
+      cur[it] = *reinterpret_cast<const float4*>((all_act ? a.b.prev_targets : a.b.cur_targets) + base_d + e);
+    }
+  }
+  const int32_t k0g = off_g[g], k0r = off_r[g];
+  const int cntg = off_g[g + 1] - k0g, cntr = off_r[g + 1] - k0r;
+
+  // ---- 1: ranks and lists
+  const bool f_env = f_env_raw != 0, f_goal = f_goal_raw != 0;
+  if (tid < D) {
+    s_inv[tid] = -1;
+    s_tab[tid] = p.dof_lower[tid];
+    s_tab[D + tid] = p.dof_upper[tid];
+    s_tab[2 * D + tid] = p.dof_default_pos[tid];
+    s_tab[3 * D + tid] = p.dof_default_vel[tid];
+  }
+  int my_cnt = 0;
+  if (DR) {  // the wrapper hands the noise the reset_buf as it stands before this step's resets (vec_env_rlgames.py:72-75)
+    const NoiseDecision d = noise_decide_cnt(a.dn, cnt_in, live, f_env);
+    my_cnt = d.cnt;
     s_dec[tid] = (d.reset ? 1 : 0) | (d.interval ? 2 : 0);
   }
   const int64_t kg = group_rank(f_goal, off_g, g, lds_b);  // (barrier inside)
   const int64_t kr = group_rank(f_env, off_r, g, lds_a);
-  const int32_t k0g = off_g[g], k0r = off_r[g];
-  const int cntg = off_g[g + 1] - k0g, cntr = off_r[g + 1] - k0r;
   if (f_goal) s_list_g[(int)(kg - k0g)] = tid;
   if (f_env) s_list_r[(int)(kr - k0r)] = tid;
   s_rank[tid] = f_env ? (int)(kr - k0r) : -1;
   if (tid < A) s_inv[p.actuated_dof_indices[tid]] = tid;
+  __syncthreads();
 
-  // ---- 1: actions -> (clamp) -> actions_out, LDS
-  const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
+  // ---- 2: dense resets.  Rows fetched first (the only loads left), then the draws, then the stores
   {
-    const int64_t base = g * GROUP * A;
-    const int nf4 = (int)(envs_here * A / 4);  // A % 4 == 0
+    const int tg = (tid + GROUP - WAVE) & (GROUP - 1);  // goal-only envs start on the second wave
+    const bool do_r = tid < cntr, do_g = tg < cntg;
+    const int il_r = do_r ? s_list_r[tid] : 0, il_g = do_g ? s_list_g[tg] : 0;
+    const int64_t ir = g * GROUP + il_r, ig = g * GROUP + il_g;
+    float gi_r[3] = {0.f, 0.f, 0.f}, ep_r[3] = {0.f, 0.f, 0.f}, oi_r[3] = {0.f, 0.f, 0.f};
+    float gi_g[3] = {0.f, 0.f, 0.f}, ep_g[3] = {0.f, 0.f, 0.f};
+    if (do_r) {
 #pragma unroll
-    for (int it = 0; it < A / 4; ++it) {
-      const int f = it * GROUP + tid;
-      if (f < nf4) {
-        float4 v = LD4S(a.actions_in + base + 4 * f);
-        if (a.dr) {  // A % 4 == 0: the four elements belong to one env
-          float vv[4] = {v.x, v.y, v.z, v.w}, c[4] = {0.f, 0.f, 0.f, 0.f};
-          float* cor = a.dn.correlated_noise + base + 4 * f;
-          if (a.dn.on_reset.enabled) {
-            const float4 q = LD4S(cor);
-            c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w;
-          }
-          const int de = s_dec[(4 * f) / A];
-          const int dec[4] = {de, de, de, de};
-          const bool dirty = noise_apply4(a.dn, dec, 4, (base >> 2) + f, vv, c);
-          v = make_float4(vv[0], vv[1], vv[2], vv[3]);
-          ST4S(a.dn.buffer + base + 4 * f, v);
-          if (dirty) *reinterpret_cast<float4*>(cor) = make_float4(c[0], c[1], c[2], c[3]);
-        }
-        if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
-          v.x = clamp_sym(v.x, p.clip_actions); v.y = clamp_sym(v.y, p.clip_actions);
-          v.z = clamp_sym(v.z, p.clip_actions); v.w = clamp_sym(v.w, p.clip_actions);
-        }
-        if (a.actions_out) *reinterpret_cast<float4*>(a.actions_out + base + 4 * f) = v;
-        *reinterpret_cast<float4*>(s_act + 4 * f) = v;
+      for (int c = 0; c < 3; ++c) {
+        gi_r[c] = a.r.goal_init_pos[ir * 3 + c];
+        ep_r[c] = a.r.env_pos[ir * 3 + c];
+        oi_r[c] = a.r.object_init_pos[ir * 3 + c];
+      }
+    }
+    if (do_g) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gi_g[c] = a.r.goal_init_pos[ig * 3 + c];
+        ep_g[c] = a.r.env_pos[ig * 3 + c];
+      }
+    }
+    if (DR && live) a.dn.counter[env] = my_cnt;  // (behind every load of this thread)
+    if (do_g) {  // goal-only ids (:324-327); an env that is in both lists keeps reset_idx's rotation (:328-329)
+      float u[4];
+      hand_draw<4>(a.r, ig, 0u, u);
+      hand_goal_write(a, ig, (int64_t)k0g + tg, u[0], u[1], gi_g, ep_g, s_rank[il_g] < 0, a.r.goal_world_pos_out, a.r.goal_rot_out);
+      a.r.goal_ids[k0g + tg] = ig;
+    }
+    if (do_r) {  // reset_idx (:397-441) without its DOF rows
+      const int64_t k = (int64_t)k0r + tid;
+      float u[8], ug[4];
+      hand_draw<8>(a.r, ir, 1u, u);  // draws 0..4 of the (n,53) table
+      hand_draw<4>(a.r, ir, 2u, ug);
+      hand_goal_write(a, ir, k, ug[0], ug[1], gi_r, ep_r, true, a.r.r_goal_world_pos_out, a.r.r_goal_rot_out);  // :401
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.r.object_pos_out[k * 3 + c] = (oi_r[c] + p.reset_position_noise * u[c]) + ep_r[c];  // :404-406
+      const q4 orot = randomize_rotation(u[3], u[4]);                                                             // :408-410
+      *reinterpret_cast<float4*>(a.r.object_rot_out + k * 4) = make_float4(orot.w, orot.x, orot.y, orot.z);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) a.r.object_vel_out[k * 6 + c] = 0.0f;  // :412-413
+      a.b.progress_buf[ir] = 0;  // :439-441
+      a.b.reset_buf[ir] = 0;
+      a.b.successes[ir] = 0.0f;
+      a.r.env_ids[k] = ir;
+    }
+    // DOF rows of the first HAND_RMAX reset envs, one float4 per lane, into LDS (their compacted rows leave in phase 6:
+    // stores issued here would sit in front of phase 3's first use of the loaded actions)
+    const int nr = cntr < HAND_RMAX ? cntr : HAND_RMAX;
+    for (int w = tid; w < nr * (D / 4); w += GROUP) {
+      const int r = w / (D / 4), j0 = 4 * (w - r * (D / 4));
+      float pos[4], vel[4];
+      hand_redraw_quad(a, tab, g * GROUP + s_list_r[r], D, j0, pos, vel);
+      *reinterpret_cast<float4*>(s_rpos + r * D + j0) = make_float4(pos[0], pos[1], pos[2], pos[3]);
+      *reinterpret_cast<float4*>(s_rvel + r * D + j0) = make_float4(vel[0], vel[1], vel[2], vel[3]);
+    }
+    if (DR && has_cor) {  // correlated_noise_buffer[reset_ids] = sample (randomize.py:379-400), same Philox key as noise_apply4
+      for (int w = tid; w < nr * (A / 4); w += GROUP) {
+        const int r = w / (A / 4), q = w - r * (A / 4);
+        const int64_t gf = (base_a >> 2) + (int64_t)s_list_r[r] * (A / 4) + q;
+        float sr[4];
+        noise_reset_samples(a.dn, gf, sr);
+        *reinterpret_cast<float4*>(s_rcor + r * A + 4 * q) = make_float4(sr[0], sr[1], sr[2], sr[3]);
       }
     }
   }
   __syncthreads();
 
-  // ---- 2: dense resets; goal-only ids first (:324-327), then reset_idx (:328-329), whose nested reset_target_pose
-  // must win on envs that are in both lists
-  if (tid < cntg) {
-    const int64_t i = g * GROUP + s_list_g[tid];
-    hand_reset_goal(a, i, (int64_t)k0g + tid, nullptr, 0u, a.r.goal_world_pos_out, a.r.goal_rot_out);
-    a.r.goal_ids[k0g + tid] = i;
+  // ---- 3: actions -> (noise) -> (clamp) -> actions_out, LDS
+#pragma unroll
+  for (int it = 0; it < A / 4; ++it) {
+    const int f = it * GROUP + tid;
+    if (f < nf4a) {
+      float4 v = act[it];
+      if (DR) {  // A % 4 == 0: the four elements belong to one env
+        const int il = (4 * f) / A;
+        float vv[4] = {v.x, v.y, v.z, v.w}, c[4] = {0.f, 0.f, 0.f, 0.f};
+        if (has_cor) { c[0] = cor[it].x; c[1] = cor[it].y; c[2] = cor[it].z; c[3] = cor[it].w; }
+        int de = s_dec[il];
+        const int lr = s_rank[il];
+        if (has_cor && lr >= 0 && lr < HAND_RMAX) {  // staged fresh sample: applied like any env's correlated noise
+          const float4 q = *reinterpret_cast<const float4*>(s_rcor + lr * A + (4 * f - il * A));
+          c[0] = q.x; c[1] = q.y; c[2] = q.z; c[3] = q.w;
+          de &= ~1;
+        }
+        const int dec[4] = {de, de, de, de};
+        const bool dirty = noise_apply4(a.dn, dec, 4, (base_a >> 2) + f, vv, c);
+        v = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        ST4S(a.dn.buffer + base_a + 4 * f, v);
+        if (dirty) *reinterpret_cast<float4*>(a.dn.correlated_noise + base_a + 4 * f) = make_float4(c[0], c[1], c[2], c[3]);
+      }
+      if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
+        v.x = clamp_sym(v.x, p.clip_actions); v.y = clamp_sym(v.y, p.clip_actions);
+        v.z = clamp_sym(v.z, p.clip_actions); v.w = clamp_sym(v.w, p.clip_actions);
+      }
+      if (a.actions_out) *reinterpret_cast<float4*>(a.actions_out + base_a + 4 * f) = v;
+      *reinterpret_cast<float4*>(s_act + 4 * f) = v;
+    }
   }
   __syncthreads();
-  if (tid < cntr) hand_reset_env_head(a, g * GROUP + s_list_r[tid], (int64_t)k0r + tid);
 
-  // ---- 3: prev/cur targets, lane-linear over the group's 256 x 24 floats
+  // ---- 4: prev/cur targets, lane-linear over the group's 256 x 24 floats
   const float one_minus = p.one_minus_act_moving_average;
   const float speed_dt = p.dof_speed_scale_dt;
-  {
-    const int64_t base = g * GROUP * D;
-    const int nf4 = (int)(envs_here * D / 4);  // D % 4 == 0
 #pragma unroll
-    for (int it = 0; it < D / 4; ++it) {
-      const int f = it * GROUP + tid;
-      if (f >= nf4) continue;
-      const int e = 4 * f;
-      const int il = e / D, j0 = e - il * D;
-      const int64_t i = g * GROUP + il;
-      const int lr = s_rank[il];
-      int kk[4];
-      bool all_act = true;
+  for (int it = 0; it < D / 4; ++it) {
+    const int f = it * GROUP + tid;
+    if (f >= nf4d) continue;
+    const int e = 4 * f;
+    const int il = e / D, j0 = e - il * D;
+    const int lr = s_rank[il];
+    int kk[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        kk[q] = s_inv[j0 + q];
-        all_act = all_act && kk[q] >= 0;
-      }
-      float prev[4], cur[4];
-      if (lr >= 0) {  // reset row: re-drawn DOF state (:415-436)
-        float up[4], uv[4] = {0.f, 0.f, 0.f, 0.f};
-        hand_draw4_at(a.r, i, 1u, 5 + j0, up);
-        if (p.reset_dof_vel_noise != 0.0f) hand_draw4_at(a.r, i, 1u, 5 + D + j0, uv);
+    for (int q = 0; q < 4; ++q) kk[q] = s_inv[j0 + q];
+    float prev[4] = {prv[it].x, prv[it].y, prv[it].z, prv[it].w};
+    float cu[4] = {cur[it].x, cur[it].y, cur[it].z, cur[it].w};  // an unactuated DOF keeps its current target
+    if (lr >= 0) {  // reset row: re-drawn DOF state (:415-436)
+      if (lr < HAND_RMAX) {
+        const float4 q = *reinterpret_cast<const float4*>(s_rpos + lr * D + j0);
+        prev[0] = q.x; prev[1] = q.y; prev[2] = q.z; prev[3] = q.w;
+      } else {
         float vel[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int j = j0 + q;
-          const float delta_max = p.dof_upper[j] - p.dof_default_pos[j];
-          const float delta_min = p.dof_lower[j] - p.dof_default_pos[j];
-          const float rand_delta = delta_min + ((delta_max - delta_min) * 0.5f) * (up[q] + 1.0f);  // :419
-          prev[q] = p.dof_default_pos[j] + p.reset_dof_pos_noise * rand_delta;                      // :421
-          vel[q] = p.dof_default_vel[j] + p.reset_dof_vel_noise * uv[q];                            // :426-429
-          cur[q] = prev[q];                                                                          // :431-432
-        }
+        hand_redraw_quad(a, tab, g * GROUP + il, D, j0, prev, vel);
         const int64_t row = ((int64_t)k0r + lr) * D + j0;
         *reinterpret_cast<float4*>(a.r.dof_pos_out + row) = make_float4(prev[0], prev[1], prev[2], prev[3]);
         *reinterpret_cast<float4*>(a.r.dof_vel_out + row) = make_float4(vel[0], vel[1], vel[2], vel[3]);
-      } else {
-        const float4 t = LD4S(a.b.prev_targets + base + e);
-        prev[0] = t.x; prev[1] = t.y; prev[2] = t.z; prev[3] = t.w;
-        if (!all_act) {  // an unactuated DOF keeps its current target
-          const float4 c4 = *reinterpret_cast<const float4*>(a.b.cur_targets + base + e);
-          cur[0] = c4.x; cur[1] = c4.y; cur[2] = c4.z; cur[3] = c4.w;
-        } else {
-          cur[0] = cur[1] = cur[2] = cur[3] = 0.0f;
-        }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (kk[q] < 0) continue;
-        const int j = j0 + q;
-        const float lo = p.dof_lower[j], hi = p.dof_upper[j];
-        const float act = s_act[il * A + kk[q]];
-        float c;
-        if (p.use_relative_control) {
-          c = tensor_clamp(prev[q] + speed_dt * act, lo, hi);  // :334-341
-        } else {
-          c = scale(act, lo, hi);                                // :343-347
-          c = p.act_moving_average * c + one_minus * prev[q];   // :348-351
-          c = tensor_clamp(c, lo, hi);                           // :352-356
-        }
-        cur[q] = c;
-        prev[q] = c;  // :358
-        s_act[il * A + kk[q]] = c;  // the action slot becomes the target slot (same thread reads and writes it)
-      }
-      ST4S(a.b.cur_targets + base + e, make_float4(cur[0], cur[1], cur[2], cur[3]));
-      ST4S(a.b.prev_targets + base + e, make_float4(prev[0], prev[1], prev[2], prev[3]));
+      for (int q = 0; q < 4; ++q) cu[q] = prev[q];  // :431-432
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (kk[q] < 0) continue;
+      const int j = j0 + q;
+      const float lo = tab.lower[j], hi = tab.upper[j];
+      const float ac = s_act[il * A + kk[q]];
+      float c;
+      if (p.use_relative_control) {
+        c = tensor_clamp(prev[q] + speed_dt * ac, lo, hi);  // :334-341
+      } else {
+        c = scale(ac, lo, hi);                                // :343-347
+        c = p.act_moving_average * c + one_minus * prev[q];   // :348-351
+        c = tensor_clamp(c, lo, hi);                           // :352-356
+      }
+      cu[q] = c;
+      prev[q] = c;  // :358
+      s_act[il * A + kk[q]] = c;  // the action slot becomes the target slot (same thread reads and writes it)
+    }
+    ST4S(a.b.cur_targets + base_d + e, make_float4(cu[0], cu[1], cu[2], cu[3]));
+    ST4S(a.b.prev_targets + base_d + e, make_float4(prev[0], prev[1], prev[2], prev[3]));
   }
   __syncthreads();
 
-  // ---- 4: targets_out = cur_targets[:, actuated] (:360-362)
-  {
-    const int64_t base = g * GROUP * A;
-    const int nf4 = (int)(envs_here * A / 4);
+  // ---- 5: targets_out = cur_targets[:, actuated] (:360-362)
 #pragma unroll
-    for (int it = 0; it < A / 4; ++it) {
-      const int f = it * GROUP + tid;
-      if (f < nf4) *reinterpret_cast<float4*>(a.targets_out + base + 4 * f) = *reinterpret_cast<const float4*>(s_act + 4 * f);
+  for (int it = 0; it < A / 4; ++it) {
+    const int f = it * GROUP + tid;
+    if (f < nf4a) *reinterpret_cast<float4*>(a.targets_out + base_a + 4 * f) = *reinterpret_cast<const float4*>(s_act + 4 * f);
+  }
+  // ---- 6: the staged rows of the reset envs: compacted dof_pos_out / dof_vel_out rows (one contiguous run per group),
+  // their refreshed correlated noise
+  {
+    const int nr = cntr < HAND_RMAX ? cntr : HAND_RMAX;
+    for (int w = tid; w < nr * (D / 4); w += GROUP) {
+      const int64_t row = (int64_t)k0r * D + 4 * w;
+      *reinterpret_cast<float4*>(a.r.dof_pos_out + row) = *reinterpret_cast<const float4*>(s_rpos + 4 * w);
+      *reinterpret_cast<float4*>(a.r.dof_vel_out + row) = *reinterpret_cast<const float4*>(s_rvel + 4 * w);
+    }
+    if (DR && has_cor) {
+      for (int w = tid; w < nr * (A / 4); w += GROUP) {
+        const int r = w / (A / 4), q = w - r * (A / 4);
+        const int64_t gf = (base_a >> 2) + (int64_t)s_list_r[r] * (A / 4) + q;
+        *reinterpret_cast<float4*>(a.dn.correlated_noise + 4 * gf) = *reinterpret_cast<const float4*>(s_rcor + r * A + 4 * q);
+      }
     }
   }
   if (g == 0 && tid == 0) {
@@ -1250,10 +1375,14 @@ static int hand_pre_physics(const oige_hand_params* params, const float* actions
     if (int rc = launch_count_flags(a.b.reset_goal_buf, num_envs, a.b.goal_workspace, s)) return rc;
   }
   if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.goal_workspace, s)) return rc;
-  if (is_allegro(params))
-    hipLaunchKernelGGL((hand_pre_kernel<OIGE_ALLEGRO_DOFS, OIGE_ALLEGRO_DOFS>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-  else
-    hipLaunchKernelGGL((hand_pre_kernel<OIGE_HAND_DOFS, OIGE_HAND_ACTIONS>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  const dim3 grid((unsigned)G), block(GROUP);
+  if (is_allegro(params)) {
+    if (a.dr) hipLaunchKernelGGL((hand_pre_kernel<OIGE_ALLEGRO_DOFS, OIGE_ALLEGRO_DOFS, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((hand_pre_kernel<OIGE_ALLEGRO_DOFS, OIGE_ALLEGRO_DOFS, false>), grid, block, 0, s, a);
+  } else {
+    if (a.dr) hipLaunchKernelGGL((hand_pre_kernel<OIGE_HAND_DOFS, OIGE_HAND_ACTIONS, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((hand_pre_kernel<OIGE_HAND_DOFS, OIGE_HAND_ACTIONS, false>), grid, block, 0, s, a);
+  }
   return check_launch("hand_pre_kernel");
 }
 
