@@ -143,7 +143,7 @@ class HandBench:
         for v in (t._hands, t._objects, t._goals):
             v.apply_resets = False
         self.actions = st["actions"]
-        self._noisy = torch.empty_like(self.actions)
+        self._noisy = self.actions.clone()  # the policy's actions; noised in place from then on (see pre())
         self._obs_clamped = torch.empty_like(t.obs_buf)
         # OIGE_BENCH_SEPARATE_DR=1: the noise as two separate launches (what VecEnvRLGames does with fused_dr = False)
         self.fused_dr = os.environ.get("OIGE_BENCH_SEPARATE_DR", "0") != "1"
@@ -164,7 +164,10 @@ class HandBench:
 
     def pre(self):
         t = self.task
-        self._noisy.copy_(self.actions)  # the policy's fresh actions (the noise is applied in place)
+        # The action noise is applied IN PLACE to the tensor the policy handed over (randomize.py:314-342), so `_noisy` carries the
+        # previous steps' noise into this one (a bounded random walk; the kernels are branch-free in the values).  Refreshing it
+        # from `actions` every step would put an 84 MB device copy -- the stand-in for the policy writing its output, not part of
+        # pre_physics_step -- inside the timed step.
         if self.fused_dr:
             t.clamp_actions_in_kernel = True
             t.pre_physics_step(self._noisy, action_noise=t._dr_randomizer.fused_actions_args(self._noisy))

@@ -878,8 +878,17 @@ __device__ __forceinline__ void hand_redraw_quad(const HandPre& a, const HandDof
 // reset envs of a group whose re-drawn rows go through LDS (computed on dense lanes); a group with more (the first step
 // after a full reset) handles the rest per lane inside the elementwise passes
 constexpr int HAND_RMAX = 64;
-#ifndef OIGE_HAND_PRE_WAVES
-#define OIGE_HAND_PRE_WAVES 4
+// threads per group of 256 envs in hand_pre_kernel (template parameter HPNT): the elementwise passes are lane-linear over
+// the group's rows, so the thread count is free; more threads = fewer float4 held per thread between the load phase and
+// the store phases.  512 pays for the ShadowHand kernel with the action noise inside (201 -> 192 us: 157 VGPRs at 256
+// threads), 256 everywhere else (AllegroHand: 94 vs 102 us).
+#ifndef OIGE_HAND_PRE_NT
+#define OIGE_HAND_PRE_NT 512
+#endif
+#ifdef OIGE_HAND_PRE_WAVES
+#define OIGE_HAND_PRE_OCC __attribute__((amdgpu_waves_per_eu(OIGE_HAND_PRE_WAVES, OIGE_HAND_PRE_WAVES)))
+#else
+#define OIGE_HAND_PRE_OCC
 #endif
 
 // pre_physics_step (:314-362) for one group of 256 envs.  Order: EVERY load first, then every store -- loads and stores
@@ -898,8 +907,8 @@ constexpr int HAND_RMAX = 64;
 //   4. prev/cur targets: reset rows take their staged DOF positions, then every actuated element gets
 //      scale -> EMA -> clamp (or the relative-control update); results land in the LDS action tile;
 //   5. the LDS tile streams out as targets_out.
-template <int D, int A, bool DR>
-__global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND_PRE_WAVES, OIGE_HAND_PRE_WAVES))) void hand_pre_kernel(const HandPre a) {
+template <int D, int A, bool DR, int HPNT>
+__global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const HandPre a) {
   __shared__ int lds_a[GROUP_TILES], lds_b[GROUP_TILES];
   __shared__ int s_list_r[GROUP], s_list_g[GROUP], s_rank[GROUP];
   __shared__ int s_inv[D];
@@ -916,7 +925,7 @@ __global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND
   const int64_t G = num_groups(a.n);
   const int32_t* off_r = a.b.reset_workspace + G * GROUP_TILES;
   const int32_t* off_g = a.b.goal_workspace + G * GROUP_TILES;
-  const bool live = env < a.n;
+  const bool live = tid < GROUP && env < a.n;
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
   const int64_t base_a = g * GROUP * A, base_d = g * GROUP * D;
   const int nf4a = (int)(envs_here * A / 4), nf4d = (int)(envs_here * D / 4);  // A % 4 == 0, D % 4 == 0
@@ -933,19 +942,20 @@ __global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND
   uint32_t amask = 0;  // uniform: bit j set = DOF j actuated
 #pragma unroll
   for (int t = 0; t < A; ++t) amask |= 1u << p.actuated_dof_indices[t];
-  float4 act[A / 4], cor[DR ? A / 4 : 1], prv[D / 4], cur[D / 4];
+  constexpr int AIT = (GROUP * (A / 4) + HPNT - 1) / HPNT, DIT = (GROUP * (D / 4) + HPNT - 1) / HPNT;
+  float4 act[AIT], cor[DR ? AIT : 1], prv[DIT], cur[DIT];
   {
     const float* cor_src = has_cor ? a.dn.correlated_noise : a.actions_in;
 #pragma unroll
-    for (int it = 0; it < A / 4; ++it) {
-      const int f = it * GROUP + tid;
+    for (int it = 0; it < AIT; ++it) {
+      const int f = it * HPNT + tid;
       const int fa = f < nf4a ? f : 0;
       act[it] = LD4S(a.actions_in + base_a + 4 * fa);
       if (DR) cor[it] = LD4S(cor_src + base_a + 4 * fa);
     }
 #pragma unroll
-    for (int it = 0; it < D / 4; ++it) {
-      const int f = it * GROUP + tid;
+    for (int it = 0; it < DIT; ++it) {
+      const int f = it * HPNT + tid;
       const int fd = f < nf4d ? f : 0;
       const int e = 4 * fd;
       const int j0 = e % D;
@@ -970,19 +980,19 @@ __global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND
   if (DR) {  // the wrapper hands the noise the reset_buf as it stands before this step's resets (vec_env_rlgames.py:72-75)
     const NoiseDecision d = noise_decide_cnt(a.dn, cnt_in, live, f_env);
     my_cnt = d.cnt;
-    s_dec[tid] = (d.reset ? 1 : 0) | (d.interval ? 2 : 0);
+    if (tid < GROUP) s_dec[tid] = (d.reset ? 1 : 0) | (d.interval ? 2 : 0);
   }
   const int64_t kg = group_rank(f_goal, off_g, g, lds_b);  // (barrier inside)
   const int64_t kr = group_rank(f_env, off_r, g, lds_a);
   if (f_goal) s_list_g[(int)(kg - k0g)] = tid;
   if (f_env) s_list_r[(int)(kr - k0r)] = tid;
-  s_rank[tid] = f_env ? (int)(kr - k0r) : -1;
+  if (tid < GROUP) s_rank[tid] = f_env ? (int)(kr - k0r) : -1;
   if (tid < A) s_inv[p.actuated_dof_indices[tid]] = tid;
   __syncthreads();
 
   // ---- 2: dense resets.  Rows fetched first (the only loads left), then the draws, then the stores
   {
-    const int tg = (tid + GROUP - WAVE) & (GROUP - 1);  // goal-only envs start on the second wave
+    const int tg = (tid + HPNT - WAVE) & (HPNT - 1);  // goal-only envs start on the second wave
     const bool do_r = tid < cntr, do_g = tg < cntg;
     const int il_r = do_r ? s_list_r[tid] : 0, il_g = do_g ? s_list_g[tg] : 0;
     const int64_t ir = g * GROUP + il_r, ig = g * GROUP + il_g;
@@ -1030,7 +1040,7 @@ __global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND
     // DOF rows of the first HAND_RMAX reset envs, one float4 per lane, into LDS (their compacted rows leave in phase 6:
     // stores issued here would sit in front of phase 3's first use of the loaded actions)
     const int nr = cntr < HAND_RMAX ? cntr : HAND_RMAX;
-    for (int w = tid; w < nr * (D / 4); w += GROUP) {
+    for (int w = tid; w < nr * (D / 4); w += HPNT) {
       const int r = w / (D / 4), j0 = 4 * (w - r * (D / 4));
       float pos[4], vel[4];
       hand_redraw_quad(a, tab, g * GROUP + s_list_r[r], D, j0, pos, vel);
@@ -1038,7 +1048,7 @@ __global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND
       *reinterpret_cast<float4*>(s_rvel + r * D + j0) = make_float4(vel[0], vel[1], vel[2], vel[3]);
     }
     if (DR && has_cor) {  // correlated_noise_buffer[reset_ids] = sample (randomize.py:379-400), same Philox key as noise_apply4
-      for (int w = tid; w < nr * (A / 4); w += GROUP) {
+      for (int w = tid; w < nr * (A / 4); w += HPNT) {
         const int r = w / (A / 4), q = w - r * (A / 4);
         const int64_t gf = (base_a >> 2) + (int64_t)s_list_r[r] * (A / 4) + q;
         float sr[4];
@@ -1051,8 +1061,8 @@ __global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND
 
   // ---- 3: actions -> (noise) -> (clamp) -> actions_out, LDS
 #pragma unroll
-  for (int it = 0; it < A / 4; ++it) {
-    const int f = it * GROUP + tid;
+  for (int it = 0; it < AIT; ++it) {
+    const int f = it * HPNT + tid;
     if (f < nf4a) {
       float4 v = act[it];
       if (DR) {  // A % 4 == 0: the four elements belong to one env
@@ -1060,6 +1070,9 @@ __global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND
         float vv[4] = {v.x, v.y, v.z, v.w}, c[4] = {0.f, 0.f, 0.f, 0.f};
         if (has_cor) { c[0] = cor[it].x; c[1] = cor[it].y; c[2] = cor[it].z; c[3] = cor[it].w; }
         int de = s_dec[il];
+#ifdef OIGE_EXP_PRE_NO_NOISE
+        de = 0;
+#endif
         const int lr = s_rank[il];
         if (has_cor && lr >= 0 && lr < HAND_RMAX) {  // staged fresh sample: applied like any env's correlated noise
           const float4 q = *reinterpret_cast<const float4*>(s_rcor + lr * A + (4 * f - il * A));
@@ -1086,8 +1099,8 @@ __global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND
   const float one_minus = p.one_minus_act_moving_average;
   const float speed_dt = p.dof_speed_scale_dt;
 #pragma unroll
-  for (int it = 0; it < D / 4; ++it) {
-    const int f = it * GROUP + tid;
+  for (int it = 0; it < DIT; ++it) {
+    const int f = it * HPNT + tid;
     if (f >= nf4d) continue;
     const int e = 4 * f;
     const int il = e / D, j0 = e - il * D;
@@ -1136,21 +1149,21 @@ __global__ __launch_bounds__(GROUP) __attribute__((amdgpu_waves_per_eu(OIGE_HAND
 
   // ---- 5: targets_out = cur_targets[:, actuated] (:360-362)
 #pragma unroll
-  for (int it = 0; it < A / 4; ++it) {
-    const int f = it * GROUP + tid;
+  for (int it = 0; it < AIT; ++it) {
+    const int f = it * HPNT + tid;
     if (f < nf4a) *reinterpret_cast<float4*>(a.targets_out + base_a + 4 * f) = *reinterpret_cast<const float4*>(s_act + 4 * f);
   }
   // ---- 6: the staged rows of the reset envs: compacted dof_pos_out / dof_vel_out rows (one contiguous run per group),
   // their refreshed correlated noise
   {
     const int nr = cntr < HAND_RMAX ? cntr : HAND_RMAX;
-    for (int w = tid; w < nr * (D / 4); w += GROUP) {
+    for (int w = tid; w < nr * (D / 4); w += HPNT) {
       const int64_t row = (int64_t)k0r * D + 4 * w;
       *reinterpret_cast<float4*>(a.r.dof_pos_out + row) = *reinterpret_cast<const float4*>(s_rpos + 4 * w);
       *reinterpret_cast<float4*>(a.r.dof_vel_out + row) = *reinterpret_cast<const float4*>(s_rvel + 4 * w);
     }
     if (DR && has_cor) {
-      for (int w = tid; w < nr * (A / 4); w += GROUP) {
+      for (int w = tid; w < nr * (A / 4); w += HPNT) {
         const int r = w / (A / 4), q = w - r * (A / 4);
         const int64_t gf = (base_a >> 2) + (int64_t)s_list_r[r] * (A / 4) + q;
         *reinterpret_cast<float4*>(a.dn.correlated_noise + 4 * gf) = *reinterpret_cast<const float4*>(s_rcor + r * A + 4 * q);
@@ -1375,13 +1388,13 @@ static int hand_pre_physics(const oige_hand_params* params, const float* actions
     if (int rc = launch_count_flags(a.b.reset_goal_buf, num_envs, a.b.goal_workspace, s)) return rc;
   }
   if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.goal_workspace, s)) return rc;
-  const dim3 grid((unsigned)G), block(GROUP);
+  const dim3 grid((unsigned)G);
   if (is_allegro(params)) {
-    if (a.dr) hipLaunchKernelGGL((hand_pre_kernel<OIGE_ALLEGRO_DOFS, OIGE_ALLEGRO_DOFS, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((hand_pre_kernel<OIGE_ALLEGRO_DOFS, OIGE_ALLEGRO_DOFS, false>), grid, block, 0, s, a);
+    if (a.dr) hipLaunchKernelGGL((hand_pre_kernel<OIGE_ALLEGRO_DOFS, OIGE_ALLEGRO_DOFS, true, GROUP>), grid, dim3(GROUP), 0, s, a);
+    else hipLaunchKernelGGL((hand_pre_kernel<OIGE_ALLEGRO_DOFS, OIGE_ALLEGRO_DOFS, false, GROUP>), grid, dim3(GROUP), 0, s, a);
   } else {
-    if (a.dr) hipLaunchKernelGGL((hand_pre_kernel<OIGE_HAND_DOFS, OIGE_HAND_ACTIONS, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((hand_pre_kernel<OIGE_HAND_DOFS, OIGE_HAND_ACTIONS, false>), grid, block, 0, s, a);
+    if (a.dr) hipLaunchKernelGGL((hand_pre_kernel<OIGE_HAND_DOFS, OIGE_HAND_ACTIONS, true, OIGE_HAND_PRE_NT>), grid, dim3(OIGE_HAND_PRE_NT), 0, s, a);
+    else hipLaunchKernelGGL((hand_pre_kernel<OIGE_HAND_DOFS, OIGE_HAND_ACTIONS, false, GROUP>), grid, dim3(GROUP), 0, s, a);
   }
   return check_launch("hand_pre_kernel");
 }

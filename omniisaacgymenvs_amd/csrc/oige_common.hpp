@@ -74,7 +74,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 __device__ __forceinline__ int64_t group_rank(bool flagged, const int32_t* group_offsets, int64_t g, int* lds4) {
   const unsigned long long mask = __ballot(flagged);
   const int w = threadIdx.x >> 6;
-  if (lane_id() == 0) lds4[w] = __popcll(mask);
+  if (lane_id() == 0 && w < GROUP_TILES) lds4[w] = __popcll(mask);  // (a workgroup may carry extra waves that own no env)
   __syncthreads();
   int before = 0;
 #pragma unroll

@@ -3,7 +3,8 @@
 import glob, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "omniisaacgymenvs_amd", "csrc")
-only = sys.argv[1:]
+only = [a for a in sys.argv[1:] if not a.startswith("-D")]
+defines = [a for a in sys.argv[1:] if a.startswith("-D")]  # e.g. -DOIGE_HAND_PRE_NT=512
 with tempfile.TemporaryDirectory() as td:
     for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
         base = os.path.basename(src)[:-4]
@@ -11,7 +12,7 @@ with tempfile.TemporaryDirectory() as td:
             continue
         s = os.path.join(td, base + ".s")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                               "--cuda-device-only", "-S", src, "-o", s], stderr=subprocess.DEVNULL)
+                               "--cuda-device-only", "-S", src, "-o", s] + defines, stderr=subprocess.DEVNULL)
         txt = open(s).read()
         for m in re.finditer(r"- \.agpr_count:.*?\.wavefront_size:", txt, flags=re.S):
             blk = m.group(0)
