@@ -96,6 +96,15 @@ __device__ __forceinline__ void cf_post_tile(const CfPost& a, float* __restrict_
     const bool die = (target_dist > 5.0f) | (rp.z < 0.5f) | (rp.z > 5.0f) | (rz.z < 0.0f);
     const bool r = (progress >= (int64_t)a.p.max_episode_length - 1) | die;
     if (live) a.b.reset_buf[env] = r ? 1 : 0;
+    // the tile's counts of the two lists the next pre_physics_step compacts (reset_buf; reset_buf | progress % 500 == 0,
+    // :183-187), so that it can skip its counting launch (OIGE_PRE_COUNTS_VALID)
+    if (a.b.reset_workspace && a.b.target_workspace) {
+      const unsigned long long mr = __ballot(live && r), mt = __ballot(live && (r || progress % 500 == 0));
+      if (lane == 0) {
+        a.b.reset_workspace[t] = __popcll(mr);
+        a.b.target_workspace[t] = __popcll(mt);
+      }
+    }
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   __syncthreads();
@@ -136,16 +145,17 @@ __global__ __launch_bounds__(GROUP) void crazyflie_count_kernel(const CfPre a) {
   }
 }
 
-// reset_idx (:313-335) rows and flags for env i -> compacted row k (the episode sums are handled by the caller)
-__device__ __forceinline__ void cf_reset_rows(const CfPre& a, int64_t i, int64_t k) {
+// reset_idx (:313-335) rows and flags for env i -> compacted row k (the episode sums are handled by the caller), from
+// the rows the caller fetched (ip = initial_root_pos[i], iq = initial_root_rot[i]): the kernels keep every load in front of
+// their first store (a load issued behind a store waits for that store's round trip)
+__device__ __forceinline__ void cf_reset_rows(const CfPre& a, int64_t i, int64_t k, const float (&ip)[3], const float4 iq) {
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   *reinterpret_cast<float4*>(a.b.dof_pos + i * 4) = z4;  // torch_rand_float(-0.0, 0.0, ...) == 0 (:316)
   *reinterpret_cast<float4*>(a.r.dof_pos_out + k * 4) = z4;
   *reinterpret_cast<float4*>(a.r.dof_vel_out + k * 4) = z4;
-  const float* ip = a.r.initial_root_pos + i * 3;
 #pragma unroll
   for (int c = 0; c < 3; ++c) a.r.root_pos_out[k * 3 + c] = ip[c] + 0.0f;
-  *reinterpret_cast<float4*>(a.r.root_rot_out + k * 4) = *reinterpret_cast<const float4*>(a.r.initial_root_rot + i * 4);
+  *reinterpret_cast<float4*>(a.r.root_rot_out + k * 4) = iq;
 #pragma unroll
   for (int c = 0; c < 6; ++c) a.r.root_vel_out[k * 6 + c] = 0.0f;
   a.b.reset_buf[i] = 0;
@@ -153,14 +163,13 @@ __device__ __forceinline__ void cf_reset_rows(const CfPre& a, int64_t i, int64_t
   a.r.env_ids[k] = i;
 }
 
-__device__ __forceinline__ void cf_set_target(const CfPre& a, int64_t i, int64_t k) {  // :300-311
+__device__ __forceinline__ void cf_set_target(const CfPre& a, int64_t i, int64_t k, const float (&ep)[3], const float4 bq) {  // :300-311
   float* tp = a.b.target_positions + i * 3;
   tp[0] = 0.0f; tp[1] = 0.0f; tp[2] = 2.0f;
-  const float* ep = a.r.env_pos + i * 3;
   a.r.ball_pos_out[k * 3 + 0] = 0.0f + ep[0];
   a.r.ball_pos_out[k * 3 + 1] = 0.0f + ep[1];
   a.r.ball_pos_out[k * 3 + 2] = (2.0f + ep[2]) + 0.0f;
-  *reinterpret_cast<float4*>(a.r.ball_rot_out + k * 4) = *reinterpret_cast<const float4*>(a.r.initial_ball_rot + i * 4);
+  *reinterpret_cast<float4*>(a.r.ball_rot_out + k * 4) = bq;
   a.r.target_ids[k] = i;
 }
 
@@ -181,58 +190,85 @@ __global__ __launch_bounds__(GROUP) void crazyflie_pre_kernel(const CfPre a) {
   const int32_t* off_r = a.b.reset_workspace + G * GROUP_TILES;
   const int32_t* off_t = a.b.target_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
+  // ---- every load of the thread first
   const bool fr = live && a.b.reset_buf[env] != 0;
   const bool ft = live && (fr || a.b.progress_buf[env] % 500 == 0);
-  const int64_t kr = group_rank(fr, off_r, g, lds_a);
-  const int64_t kt = group_rank(ft, off_t, g, lds_b);
-  // these rows are a handful of scalars per env: the flagged lanes write them themselves (no dense-lane pass needed)
-  if (fr) cf_reset_rows(a, env, kr);
-  if (ft) cf_set_target(a, env, kt);
-  // episode sums of the reset envs: per-group partial sums for extras (:331-335), then zero
+  const int64_t le = live ? env : 0;  // dead lanes shadow env 0, never store
+  const float4 av4 = *reinterpret_cast<const float4*>(a.actions_in + le * 4);
+  // (reset envs read their filter states too and ignore them: reset_idx zeroes both, :328-329)
+  const float4 cd_in = *reinterpret_cast<const float4*>(a.b.thrust_cmds_damp + le * 4);
+  const float4 rd_in = LD4S(a.b.thrust_rot_damp + le * 4);
+  const float4 r4 = *reinterpret_cast<const float4*>(a.root_rot + le * 4);
+  const float tn[4] = {a.r.thrust_noise4[0], a.r.thrust_noise4[1], a.r.thrust_noise4[2], a.r.thrust_noise4[3]};  // (a device tensor)
+  const int32_t total_r = off_r[G], total_t = off_t[G];
+  float ip[3] = {0.f, 0.f, 0.f}, ep[3] = {0.f, 0.f, 0.f};
+  float4 iq = make_float4(0.f, 0.f, 0.f, 0.f), bq = iq;
   float es[CE];
 #pragma unroll
+  for (int k = 0; k < CE; ++k) es[k] = 0.0f;
+  if (fr) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ip[c] = a.r.initial_root_pos[env * 3 + c];
+    iq = *reinterpret_cast<const float4*>(a.r.initial_root_rot + env * 4);
+#pragma unroll
+    for (int k = 0; k < CE; ++k) es[k] = a.b.episode_sums[(int64_t)k * a.n + env];
+  }
+  if (ft) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ep[c] = a.r.env_pos[env * 3 + c];
+    bq = *reinterpret_cast<const float4*>(a.r.initial_ball_rot + env * 4);
+  }
+  const int64_t kr = group_rank(fr, off_r, g, lds_a);
+  const int64_t kt = group_rank(ft, off_t, g, lds_b);
+  // episode sums of the reset envs: per-group partial sums for extras (:331-335); consumed before the first store so
+  // that the wait for these (conditional) loads is not also a wait for stores
+#pragma unroll
   for (int k = 0; k < CE; ++k) {
-    es[k] = fr ? a.b.episode_sums[(int64_t)k * a.n + env] : 0.0f;
     const float s = wave_sum_cf(es[k]);
     if (lane_id() == 0) s_part[tid >> 6][k] = s;
-    if (fr) a.b.episode_sums[(int64_t)k * a.n + env] = 0.0f;
   }
   __syncthreads();
+  // ---- stores from here on
   if (tid < CE) {
     float s = 0.0f;
 #pragma unroll
     for (int w = 0; w < GROUP_TILES; ++w) s += s_part[w][tid];
     a.b.reduce_workspace[g * CE + tid] = s;
   }
+  // these rows are a handful of scalars per env: the flagged lanes write them themselves (no dense-lane pass needed)
+  if (fr) {
+    cf_reset_rows(a, env, kr, ip, iq);
+#pragma unroll
+    for (int k = 0; k < CE; ++k) a.b.episode_sums[(int64_t)k * a.n + env] = 0.0f;  // then zero (:335)
+  }
+  if (ft) cf_set_target(a, env, kt, ep, bq);
   if (live) {  // :174-251
-    float4 av4 = *reinterpret_cast<const float4*>(a.actions_in + env * 4);
     float av[4] = {av4.x, av4.y, av4.z, av4.w};
     if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) av[c] = clamp_sym(av[c], p.clip_actions);
     }
     ST4S(a.b.actions + env * 4, make_float4(av[0], av[1], av[2], av[3]));  // self.actions = actions (:180)
-    float4 cd4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = cd4;
-    if (!fr) {  // reset_idx zeroed both filter states of the reset envs (:328-329)
-      cd4 = *reinterpret_cast<const float4*>(a.b.thrust_cmds_damp + env * 4);
-      rd4 = LD4S(a.b.thrust_rot_damp + env * 4);
-    }
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 cd4 = fr ? z4 : cd_in, rd4 = fr ? z4 : rd_in;  // reset_idx zeroed both filter states of the reset envs
     const float cd[4] = {cd4.x, cd4.y, cd4.z, cd4.w}, rd[4] = {rd4.x, rd4.y, rd4.z, rd4.w};
-    const float4 r4 = *reinterpret_cast<const float4*>(a.root_rot + env * 4);
     const q4 rot{r4.x, r4.y, r4.z, r4.w};
     const f3 rx = quat_rotate(rot, f3{1.0f, 0.0f, 0.0f}), ry = quat_rotate(rot, f3{0.0f, 1.0f, 0.0f});
     const f3 rz = quat_rotate(rot, f3{0.0f, 0.0f, 1.0f});
     float ncd[4], nrd[4], th[12];
+    // tau[tau > 1] = 1 applied to the two constants before the per-motor choice: picked straight from the argument block,
+    // the choice becomes a run-time-indexed VECTOR load of it, issued behind the stores above
+    const float tau_down = p.motor_tau_down > 1.0f ? 1.0f : p.motor_tau_down;
+    const float tau_up = p.motor_tau_up > 1.0f ? 1.0f : p.motor_tau_up;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float cl = clamp_sym(av[j], 1.0f);                 // torch.clamp(actions, min=-1.0, max=1.0)
       const float cmd = (cl + 1.0f) / 2.0f;
-      float tau = cmd < cd[j] ? p.motor_tau_down : p.motor_tau_up;
-      tau = tau > 1.0f ? 1.0f : tau;
+      const float tau = cmd < cd[j] ? tau_down : tau_up;
       const float trot = __builtin_sqrtf(cmd);                 // thrust_cmds ** 0.5
       nrd[j] = tau * (trot - rd[j]) + rd[j];
       float c2 = nrd[j] * nrd[j];                              // thrust_rot_damp ** 2
-      c2 = c2 + cmd * a.r.thrust_noise4[j];
+      c2 = c2 + cmd * tn[j];
       ncd[j] = (c2 != c2) ? c2 : (c2 < 0.0f ? 0.0f : (c2 > 1.0f ? 1.0f : c2));
       const float thr = p.thrust_max[j] * ncd[j];
       // matmul(rot_matrix, (0, 0, thr)): rows of the matrix are the body axes, so the result is their z components * thr
@@ -250,24 +286,33 @@ __global__ __launch_bounds__(GROUP) void crazyflie_pre_kernel(const CfPre a) {
         make_float4(ncd[0] * p.prop_max_rot, -1.0f * (ncd[1] * p.prop_max_rot), ncd[2] * p.prop_max_rot, -1.0f * (ncd[3] * p.prop_max_rot));
   }
   if (g == 0 && tid == 0) {
-    *a.r.count = (int64_t)off_r[G];
-    *a.r.target_count = (int64_t)off_t[G];
+    *a.r.count = (int64_t)total_r;
+    *a.r.target_count = (int64_t)total_t;
   }
 }
 
 // extras["episode"][key] = mean(episode_sums[key][env_ids]) / max_episode_length (:331-334): groups folded in order
-__global__ __launch_bounds__(CE * WAVE) void crazyflie_extras_kernel(const CfPre a) {
-  const int k = threadIdx.x >> 6, lane = lane_id();
+constexpr int CF_EX_PER = 1024;  // threads per episode-sum key: one workgroup per key
+__global__ __launch_bounds__(CF_EX_PER) void crazyflie_extras_kernel(const CfPre a) {
+  __shared__ double part[CF_EX_PER / WAVE];
+  const int k = blockIdx.x, j = threadIdx.x, lane = lane_id();
   const int64_t G = num_groups(a.n);
   double acc = 0.0;
-  // same left-to-right sum per lane; unrolled so that the independent loads of eight iterations are in flight together
-  // (one wave, 64 dependent load-add rounds at 1 M envs: this launch is pure latency)
-#pragma unroll 8
-  for (int64_t i = lane; i < G; i += WAVE) acc += (double)a.b.reduce_workspace[i * CE + k];
+  // f64 partial sums; at 1 M envs every thread has four independent loads (with one wave per key this launch was 64
+  // dependent load-add rounds: 16 us of pure latency)
+#pragma unroll 4
+  for (int64_t i = j; i < G; i += CF_EX_PER) acc += (double)a.b.reduce_workspace[i * CE + k];
 #pragma unroll
   for (int off = WAVE / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, WAVE);
-  const int32_t count = a.b.reset_workspace[G * GROUP_TILES + G];
-  if (lane == 0 && count > 0) a.b.extras[k] = ((float)acc / (float)count) / (float)a.p.max_episode_length;
+  if (lane == 0) part[j / WAVE] = acc;
+  __syncthreads();
+  if (j == 0) {
+    double tot = 0.0;
+#pragma unroll
+    for (int w = 0; w < CF_EX_PER / WAVE; ++w) tot += part[w];
+    const int32_t count = a.b.reset_workspace[G * GROUP_TILES + G];
+    if (count > 0) a.b.extras[k] = ((float)tot / (float)count) / (float)a.p.max_episode_length;
+  }
 }
 
 __global__ __launch_bounds__(256) void crazyflie_reset_idx_kernel(const CfPre a, int64_t max_ids) {
@@ -275,7 +320,8 @@ __global__ __launch_bounds__(256) void crazyflie_reset_idx_kernel(const CfPre a,
   if (k >= max_ids || k >= *a.r.count) return;
   const int64_t i = a.r.env_ids[k];
   if (i < 0 || i >= a.n) return;
-  cf_reset_rows(a, i, k);
+  const float ip[3] = {a.r.initial_root_pos[i * 3], a.r.initial_root_pos[i * 3 + 1], a.r.initial_root_pos[i * 3 + 2]};
+  cf_reset_rows(a, i, k, ip, *reinterpret_cast<const float4*>(a.r.initial_root_rot + i * 4));
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   *reinterpret_cast<float4*>(a.b.thrust_cmds_damp + i * 4) = z4;
   *reinterpret_cast<float4*>(a.b.thrust_rot_damp + i * 4) = z4;
@@ -287,7 +333,8 @@ __global__ __launch_bounds__(256) void crazyflie_set_targets_kernel(const CfPre 
   if (k >= max_ids || k >= *a.r.target_count) return;
   const int64_t i = a.r.target_ids[k];
   if (i < 0 || i >= a.n) return;
-  cf_set_target(a, i, k);
+  const float ep[3] = {a.r.env_pos[i * 3], a.r.env_pos[i * 3 + 1], a.r.env_pos[i * 3 + 2]};
+  cf_set_target(a, i, k, ep, *reinterpret_cast<const float4*>(a.r.initial_ball_rot + i * 4));
 }
 
 static int check_cf(const oige_crazyflie_params* p, const oige_crazyflie_buffers* b, int64_t n, const char* who) {
@@ -381,12 +428,14 @@ int oige_crazyflie_pre_physics(const oige_crazyflie_params* params, const float*
   const int64_t G = num_groups(num_envs);
   if (G == 0) return OIGE_OK;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(crazyflie_count_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
-  if (int rc = check_launch("crazyflie_count_kernel")) return rc;
+  if (!(flags & OIGE_PRE_COUNTS_VALID)) {  // the post kernel's DONE stage leaves the same tile counts
+    hipLaunchKernelGGL(crazyflie_count_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    if (int rc = check_launch("crazyflie_count_kernel")) return rc;
+  }
   if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.target_workspace, s)) return rc;
   hipLaunchKernelGGL(crazyflie_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   if (int rc = check_launch("crazyflie_pre_kernel")) return rc;
-  hipLaunchKernelGGL(crazyflie_extras_kernel, dim3(1), dim3(CE * WAVE), 0, s, a);
+  hipLaunchKernelGGL(crazyflie_extras_kernel, dim3(CE), dim3(CF_EX_PER), 0, s, a);
   return check_launch("crazyflie_extras_kernel");
 }
 

@@ -165,6 +165,10 @@ class CrazyflieTask(RLTask):
         rc = _lib.load().oige_crazyflie_post_physics(C.byref(p), C.byref(s), C.byref(b), self._num_envs, stages,
                                                      _lib.current_stream(self.obs_buf.device))
         _lib.check(rc, "oige_crazyflie_post_physics")
+        if stages & _lib.STAGE_DONE:  # the DONE stage leaves the tile counts of both lists pre_physics_step compacts
+            self._mark_counts(self.reset_buf, self.progress_buf)
+        elif stages & _lib.STAGE_PROGRESS:  # progress moved under the target list's counts (a raw-pointer write: no version bump)
+            self._counts_key = None
 
     # ------------------------------------------------------------------ RLTask methods
     def get_observations(self) -> dict:
@@ -234,6 +238,8 @@ class CrazyflieTask(RLTask):
             set_target_ids = (self.progress_buf % 500 == 0).nonzero(as_tuple=False).squeeze(-1)
             if len(set_target_ids) > 0:
                 self.set_targets(set_target_ids)
+        elif self._counts_valid(self.reset_buf, self.progress_buf):
+            flags |= _lib.PRE_COUNTS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS
         self._noise4 = (0.01 * torch.randn(4, dtype=torch.float32, device=self._device)).contiguous()  # :197
