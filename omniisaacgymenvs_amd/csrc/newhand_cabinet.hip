@@ -251,12 +251,33 @@ __device__ __forceinline__ void nh_reset_rows(const NhPre& a, int64_t i, int64_t
   a.r.env_ids[k] = i;
 }
 
+// new joint position j of reset env i on its own (the Philox block that holds draw j): for the reset rows past NH_RMAX
+template <int D>
+__device__ __forceinline__ float nh_reset_pos(const NhPre& a, int64_t i, int j, float dflt, float lo, float hi) {
+  const u4 c{(uint32_t)i, (uint32_t)(j >> 2), (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};
+  const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
+  const uint32_t w = (j & 3) == 0 ? x.x : (j & 3) == 1 ? x.y : (j & 3) == 2 ? x.z : x.w;
+  return tensor_clamp(dflt + 0.25f * (u01(w) - 0.5f), lo, hi);
+}
+
+// reset envs of a group whose new joint rows are staged in LDS; the synthetic bench state resets 20-25 % of a group per
+// step (51-64 +- 7), the reference one env in a thousand; a group with more (the first step after a full reset) handles the
+// rest element by element
+constexpr int NH_RMAX = 96;
+
+// pre_physics_step for one group of 256 envs.  Order (r02): EVERY lane-linear load first (the group's actions, 256 x A
+// floats, and targets, 256 x D floats, as float4 pieces), then the stores -- a load issued behind a store waits for that
+// store's round trip, and the r01 kernel ran reset stores -> action loads -> action stores -> target loads, with one
+// 4-byte gather of `actions_in` per target element on top (26 per thread).  The clamped actions are staged in LDS for the
+// target walk (r01 tried that with the full 256-row reset staging beside it: 53 KB, three workgroups per CU; the reset
+// staging is now capped at NH_RMAX rows: 39 KB, four).
 template <int D, int A>
 __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre a) {
   __shared__ int lds4[GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
-  __shared__ float s_rows[GROUP * D];  // new joint positions of the group's reset envs, compacted row order
-  __shared__ float s_lo[D], s_hi[D], s_rate[D];
+  __shared__ __align__(16) float s_rows[NH_RMAX * D];  // new joint positions of the group's reset envs, compacted row order
+  __shared__ __align__(16) float s_act[GROUP * A];      // the group's (clamped) actions
+  __shared__ float s_lo[D], s_hi[D], s_rate[D], s_def[D];
   __shared__ int s_inv[D];  // joint -> action column, -1: not actuated
   const oige_newhand_cabinet_params& p = a.p;
   const int tid = threadIdx.x;
@@ -265,10 +286,47 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   const int64_t G = num_groups(a.n);
   const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
+  const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
+  const bool clampa = a.flags & OIGE_PRE_CLAMP_ACTIONS;
+  const int atotal = (int)envs_here * A, ttotal = (int)envs_here * D;
+  const int64_t abase = g * GROUP * A, tbase = g * GROUP * D;
+  constexpr int AIT = (GROUP * A / 4 + GROUP - 1) / GROUP, TIT = (GROUP * D / 4 + GROUP - 1) / GROUP;
+
+  // ---- 0: loads
   const bool flagged = live && a.b.reset_buf[env] != 0;
-  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
   const int32_t k0 = group_offsets[g];
   const int cnt = group_offsets[g + 1] - k0;
+  const int32_t total_resets = group_offsets[G];
+  float av[AIT][4], tv[TIT][4];
+#pragma unroll
+  for (int it = 0; it < AIT; ++it) {
+    const int e = 4 * (it * GROUP + tid);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) av[it][c] = 0.f;
+    if (e + 3 < atotal) {
+      const float4 v = *reinterpret_cast<const float4*>(a.actions_in + abase + e);
+      av[it][0] = v.x; av[it][1] = v.y; av[it][2] = v.z; av[it][3] = v.w;
+    } else {
+      for (int c = 0; c < 4; ++c)
+        if (e + c < atotal) av[it][c] = a.actions_in[abase + e + c];
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < TIT; ++it) {
+    const int e = 4 * (it * GROUP + tid);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tv[it][c] = 0.f;
+    if (e + 3 < ttotal) {
+      const float4 t4 = LD4S(a.b.dof_targets + tbase + e);
+      tv[it][0] = t4.x; tv[it][1] = t4.y; tv[it][2] = t4.z; tv[it][3] = t4.w;
+    } else {
+      for (int c = 0; c < 4; ++c)
+        if (e + c < ttotal) tv[it][c] = a.b.dof_targets[tbase + e + c];
+    }
+  }
+
+  // ---- 1: ranks, lists, per-joint tables
+  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
 #pragma unroll
@@ -276,6 +334,7 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
     if (tid == j) {
       s_lo[j] = p.dof_lower[j];
       s_hi[j] = p.dof_upper[j];
+      s_def[j] = p.default_dof_pos[j];
       s_rate[j] = p.dof_speed_scales[j] * p.dt;  // left to right: speed_scales * dt * actions * action_scale
     }
   if (tid >= 64 && tid < 64 + D) {
@@ -287,15 +346,78 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   }
   __syncthreads();
 
-  if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env; its new joint row goes to LDS row j
-    const int64_t i = g * GROUP + s_list[tid];
+  // ---- 2: resets on dense lanes: thread j takes the group's j-th flagged env; its new joint row goes to LDS row j (past
+  // NH_RMAX: straight to memory)
+  wait_loads_done();
+  if (tid < cnt) {
+    const int64_t i = g * GROUP + s_list[tid], kk = (int64_t)k0 + tid;
     float u[NMAX + 2];
     nh_draws<D>(a, i, u);
-    nh_reset_rows<D>(a, i, (int64_t)k0 + tid, u, s_rows + tid * D);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      const float pos = tensor_clamp(p.default_dof_pos[j] + 0.25f * (u[j] - 0.5f), p.dof_lower[j], p.dof_upper[j]);
+      if (tid < NH_RMAX) {
+        s_rows[tid * D + j] = pos;
+      } else {
+        a.r.dof_pos_out[kk * D + j] = pos;
+        a.r.dof_vel_out[kk * D + j] = 0.0f;
+      }
+    }
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(a.r.cabinet_dof_pos_out + kk * 4) = z4;
+    *reinterpret_cast<float4*>(a.r.cabinet_dof_vel_out + kk * 4) = z4;
+    a.b.reset_buf[i] = 0;
+    a.b.progress_buf[i] = 0;
+    a.r.env_ids[kk] = i;
   }
-  __syncthreads();  // the reset envs' new rows are visible to the whole workgroup
-  {  // dof_pos_out / dof_vel_out rows k0 .. k0 + cnt: one contiguous run each, written lane-linearly
-    const int run = cnt * D;
+
+  // ---- 3: actions.clone() (+ the wrapper's clamp), and the LDS copy the target walk reads
+#pragma unroll
+  for (int it = 0; it < AIT; ++it) {
+    const int e = 4 * (it * GROUP + tid);
+    if (e >= atotal) continue;
+    if (clampa) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) av[it][c] = clamp_sym(av[it][c], p.clip_actions);
+    }
+    if (e + 3 < atotal) {
+      ST4S(a.b.actions + abase + e, make_float4(av[it][0], av[it][1], av[it][2], av[it][3]));
+    } else {
+      for (int c = 0; c < 4; ++c)
+        if (e + c < atotal) a.b.actions[abase + e + c] = av[it][c];
+    }
+    *reinterpret_cast<float4*>(s_act + e) = make_float4(av[it][0], av[it][1], av[it][2], av[it][3]);
+  }
+  __syncthreads();  // the reset envs' new rows and the group's actions are visible to the whole workgroup
+
+  // ---- 4: targets: joint j integrates action column s_inv[j] (none: unchanged)
+#pragma unroll
+  for (int it = 0; it < TIT; ++it) {
+    const int e = 4 * (it * GROUP + tid);
+    if (e >= ttotal) continue;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ee = e + c;
+      if (ee >= ttotal) continue;
+      const int il = ee / D, jj = ee - il * D;
+      const int rk = s_rank[il];
+      if (rk >= 0)  // dof_targets[env_ids] = pos (reset_idx), then this step's integration
+        tv[it][c] = rk < NH_RMAX ? s_rows[rk * D + jj] : nh_reset_pos<D>(a, g * GROUP + il, jj, s_def[jj], s_lo[jj], s_hi[jj]);
+      const int ja = s_inv[jj];
+      if (ja < 0) continue;
+      tv[it][c] = tensor_clamp(tv[it][c] + (s_rate[jj] * s_act[il * A + ja]) * p.action_scale, s_lo[jj], s_hi[jj]);
+    }
+    if (e + 3 < ttotal) {
+      ST4S(a.b.dof_targets + tbase + e, make_float4(tv[it][0], tv[it][1], tv[it][2], tv[it][3]));
+    } else {
+      for (int c = 0; c < 4; ++c)
+        if (e + c < ttotal) a.b.dof_targets[tbase + e + c] = tv[it][c];
+    }
+  }
+
+  // ---- 5: dof_pos_out / dof_vel_out rows k0 .. k0 + min(cnt, NH_RMAX): one contiguous run each, written lane-linearly
+  {
+    const int run = (cnt < NH_RMAX ? cnt : NH_RMAX) * D;
     float* dp = a.r.dof_pos_out + (int64_t)k0 * D;
     float* dv = a.r.dof_vel_out + (int64_t)k0 * D;
     for (int e = tid; e < run; e += GROUP) {
@@ -303,72 +425,23 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
       dv[e] = 0.0f;
     }
   }
-
-  const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
-  const bool clampa = a.flags & OIGE_PRE_CLAMP_ACTIONS;
-  {  // actions.clone() (+ the wrapper's clamp): the group's 256 x A floats as float4 pieces
-    const int total = (int)envs_here * A;
-    const int64_t abase = g * GROUP * A;
-#pragma unroll
-    for (int it = 0; it < (GROUP * A / 4 + GROUP - 1) / GROUP; ++it) {
-      const int e = 4 * (it * GROUP + tid);
-      if (e >= total) continue;
-      if (e + 3 < total) {
-        float4 v = *reinterpret_cast<const float4*>(a.actions_in + abase + e);
-        if (clampa) {
-          v.x = clamp_sym(v.x, p.clip_actions); v.y = clamp_sym(v.y, p.clip_actions);
-          v.z = clamp_sym(v.z, p.clip_actions); v.w = clamp_sym(v.w, p.clip_actions);
-        }
-        ST4S(a.b.actions + abase + e, v);
-      } else {
-        for (int c = 0; c < 4; ++c)
-          if (e + c < total) {
-            const float v = a.actions_in[abase + e + c];
-            a.b.actions[abase + e + c] = clampa ? clamp_sym(v, p.clip_actions) : v;
-          }
-      }
-    }
-  }
-  {  // targets: the group's 256 x D floats as float4 pieces; joint j integrates action column s_inv[j] (none: unchanged)
-    const int total = (int)envs_here * D;
-    const int64_t tbase = g * GROUP * D;
-#pragma unroll
-    for (int it = 0; it < (GROUP * D / 4 + GROUP - 1) / GROUP; ++it) {
-      const int e = 4 * (it * GROUP + tid);
-      if (e >= total) continue;
-      float tv[4] = {0.f, 0.f, 0.f, 0.f};
-      const bool vec = e + 3 < total;
-      if (vec) {
-        const float4 t4 = LD4S(a.b.dof_targets + tbase + e);
-        tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
-      } else {
-        for (int c = 0; c < 4; ++c)
-          if (e + c < total) tv[c] = a.b.dof_targets[tbase + e + c];
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int ee = e + c;
-        if (ee >= total) continue;
-        const int il = ee / D, jj = ee - il * D;
-        const int rk = s_rank[il];
-        if (rk >= 0) tv[c] = s_rows[rk * D + jj];  // dof_targets[env_ids] = pos (reset_idx), then this step's integration
-        const int ja = s_inv[jj];
-        if (ja < 0) continue;
-        float av = a.actions_in[(g * GROUP + il) * A + ja];
-        if (clampa) av = clamp_sym(av, p.clip_actions);
-        tv[c] = tensor_clamp(tv[c] + (s_rate[jj] * av) * p.action_scale, s_lo[jj], s_hi[jj]);
-      }
-      if (vec) {
-        ST4S(a.b.dof_targets + tbase + e, make_float4(tv[0], tv[1], tv[2], tv[3]));
-      } else {
-        for (int c = 0; c < 4; ++c)
-          if (e + c < total) a.b.dof_targets[tbase + e + c] = tv[c];
-      }
-    }
-  }
   if (g == 0 && tid == 0) {
-    *a.r.count = (int64_t)group_offsets[G];
-    *a.r.prop_count = (int64_t)group_offsets[G] * p.num_props;
+    *a.r.count = (int64_t)total_resets;
+    *a.r.prop_count = (int64_t)total_resets * p.num_props;
+  }
+  // ---- 6: prop rows of the reset envs, one prop per lane.  Last: these loads sit behind the kernel's stores, and nothing waits
+  // for this part
+  {
+    const int P = p.num_props;
+    for (int w = tid; w < cnt * P; w += GROUP) {
+      const int r = w / P, j = w - r * P;
+      const int64_t src = (g * GROUP + s_list[r]) * P + j, dst = ((int64_t)k0 + r) * P + j;
+      const float px = a.r.default_prop_pos[src * 3], py = a.r.default_prop_pos[src * 3 + 1], pz = a.r.default_prop_pos[src * 3 + 2];
+      const float4 pr = *reinterpret_cast<const float4*>(a.r.default_prop_rot + src * 4);
+      a.r.prop_ids[dst] = src;
+      a.r.prop_pos_out[dst * 3] = px; a.r.prop_pos_out[dst * 3 + 1] = py; a.r.prop_pos_out[dst * 3 + 2] = pz;
+      *reinterpret_cast<float4*>(a.r.prop_rot_out + dst * 4) = pr;
+    }
   }
 }
 

@@ -71,6 +71,13 @@ __device__ __forceinline__ int wave_sum(int v) {
 // Rank (position in the ascending compacted id list) of env `env` if `flagged`, for a
 // 256-thread workgroup that owns group `g` (envs [256g, 256g+256)).  Needs 4 ints of LDS.
 // Every thread of the workgroup must call it.  Returns -1 for unflagged lanes.
+// Every vector-memory operation this wave has issued is complete (s_waitcnt vmcnt(0); the other counters left alone).
+// Placed once behind a kernel's load phase, in front of its first store: the compiler's own wait-count tracking then knows
+// that no load is pending.  Without it, a register filled by a load inside a conditional block keeps its "pending" mark along
+// every path that skipped the block, and each later use gets a full `s_waitcnt vmcnt(0)` of its own -- which, behind a
+// store, is a wait for that store's round trip to HBM (loads and stores share the counter).
+__device__ __forceinline__ void wait_loads_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 __device__ __forceinline__ int64_t group_rank(bool flagged, const int32_t* group_offsets, int64_t g, int* lds4) {
   const unsigned long long mask = __ballot(flagged);
   const int w = threadIdx.x >> 6;
