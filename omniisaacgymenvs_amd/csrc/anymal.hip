@@ -186,12 +186,13 @@ struct AnymalFlatPre {
   uint32_t flags;
 };
 
-// the per-env scalars of reset_idx (:196-231) for env i landing in compacted row k; u3 = U[0,1) draws for x, y, yaw
-__device__ __forceinline__ void anymal_flat_reset_head(const AnymalFlatPre& a, int64_t i, int64_t k, const float (&u3)[3]) {
+// the per-env scalars of reset_idx (:196-231) for env i landing in compacted row k; u3 = U[0,1) draws for x, y, yaw;
+// ip / iq = initial_root_pos[i] / initial_root_rot[i], fetched by the caller in front of its first store
+__device__ __forceinline__ void anymal_flat_reset_head(const AnymalFlatPre& a, int64_t i, int64_t k, const float (&u3)[3],
+                                                       const float (&ip)[3], const float4 iq) {
   const oige_anymal_flat_params& p = a.p;
-  const float* ip = a.r.initial_root_pos + i * 3;
   a.r.root_pos_out[k * 3 + 0] = ip[0]; a.r.root_pos_out[k * 3 + 1] = ip[1]; a.r.root_pos_out[k * 3 + 2] = ip[2];
-  *reinterpret_cast<float4*>(a.r.root_rot_out + k * 4) = *reinterpret_cast<const float4*>(a.r.initial_root_rot + i * 4);
+  *reinterpret_cast<float4*>(a.r.root_rot_out + k * 4) = iq;
 #pragma unroll
   for (int c = 0; c < 6; ++c) a.r.root_vel_out[k * 6 + c] = 0.0f;  // :205
 #pragma unroll
@@ -201,36 +202,64 @@ __device__ __forceinline__ void anymal_flat_reset_head(const AnymalFlatPre& a, i
   a.r.env_ids[k] = i;
 }
 
+// Order (r02): every load in front of the first store (the group's action and target quads, then -- after the ranks -- the
+// dense lanes' initial rows), per-DOF rows of the params in LDS (indexed in place by a run-time column they are vector
+// loads of the argument block): a load issued behind a store waits for that store's round trip.
 __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlatPre a) {
   __shared__ int lds4[GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
+  __shared__ float s_lo[FD], s_hi[FD], s_def[FD];
   const oige_anymal_flat_params& p = a.p;
   const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
   const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
   const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
-  const bool flagged = env < a.n && a.b.reset_buf[env] != 0;  // :184
-  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
-  const int32_t k0 = group_offsets[g];
-  const int cnt = group_offsets[g + 1] - k0;
-  if (flagged) s_list[(int)(k - k0)] = tid;
-  s_rank[tid] = flagged ? (int)(k - k0) : -1;
-  __syncthreads();
-
-  // dense lanes: thread j takes the group's j-th flagged env
-  if (tid < cnt) {
-    const int64_t i = g * GROUP + s_list[tid];
-    const u4 c{(uint32_t)i, 3u, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};  // draws 12, 13, 14: x, y, yaw
-    const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
-    const float u3[3] = {u01(x.x), u01(x.y), u01(x.z)};
-    anymal_flat_reset_head(a, i, (int64_t)k0 + tid, u3);
-  }
-
-  // lane-linear over the group's 256 x 12 floats
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
   const int64_t base = g * GROUP * FD;
   const int nf4 = (int)(envs_here * FD / 4);
+  // ---- loads
+  const bool flagged = env < a.n && a.b.reset_buf[env] != 0;  // :184
+  const int32_t k0 = group_offsets[g];
+  const int cnt = group_offsets[g + 1] - k0;
+  const int32_t total = group_offsets[G];
+  float4 av[FD / 4], ct4[FD / 4];
+#pragma unroll
+  for (int it = 0; it < FD / 4; ++it) {
+    const int f = it * GROUP + tid;
+    const int e = 4 * (f < nf4 ? f : 0);  // idle lanes re-read the group's first quad
+    av[it] = *reinterpret_cast<const float4*>(a.actions_in + base + e);
+    ct4[it] = LD4S(a.b.current_targets + base + e);  // (reset rows read theirs too and ignore it)
+  }
+  if (tid < FD) {
+    s_lo[tid] = p.dof_lower[tid];
+    s_hi[tid] = p.dof_upper[tid];
+    s_def[tid] = p.default_dof_pos[tid];
+  }
+  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
+  if (flagged) s_list[(int)(k - k0)] = tid;
+  s_rank[tid] = flagged ? (int)(k - k0) : -1;
+  __syncthreads();
+  wait_loads_done();  // (in front of the dense lanes' block: inside it, waves without a dense lane would skip the wait)
+  const bool dense = tid < cnt;  // dense lanes: thread j takes the group's j-th flagged env
+  const int64_t di = g * GROUP + (dense ? s_list[tid] : 0);
+  float ip[3] = {0.f, 0.f, 0.f};
+  float4 iq = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (dense) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ip[c] = a.r.initial_root_pos[di * 3 + c];
+    iq = *reinterpret_cast<const float4*>(a.r.initial_root_rot + di * 4);
+  }
+
+  // ---- stores
+  if (dense) {
+    const u4 c{(uint32_t)di, 3u, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};  // draws 12, 13, 14: x, y, yaw
+    const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
+    const float u3[3] = {u01(x.x), u01(x.y), u01(x.z)};
+    anymal_flat_reset_head(a, di, (int64_t)k0 + tid, u3, ip, iq);
+  }
+
+  // lane-linear over the group's 256 x 12 floats
 #pragma unroll
   for (int it = 0; it < FD / 4; ++it) {
     const int f = it * GROUP + tid;
@@ -238,13 +267,13 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
     const int e = 4 * f;
     const int il = e / FD, j0 = e - il * FD;
     const int lr = s_rank[il];
-    float4 av = *reinterpret_cast<const float4*>(a.actions_in + base + e);
+    float4 v = av[it];
     if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
-      av.x = clamp_sym(av.x, p.clip_actions); av.y = clamp_sym(av.y, p.clip_actions);
-      av.z = clamp_sym(av.z, p.clip_actions); av.w = clamp_sym(av.w, p.clip_actions);
+      v.x = clamp_sym(v.x, p.clip_actions); v.y = clamp_sym(v.y, p.clip_actions);
+      v.z = clamp_sym(v.z, p.clip_actions); v.w = clamp_sym(v.w, p.clip_actions);
     }
-    *reinterpret_cast<float4*>(a.actions_out + base + e) = av;  // self.actions[:] = actions (:189)
-    float ct[4];
+    *reinterpret_cast<float4*>(a.actions_out + base + e) = v;  // self.actions[:] = actions (:189)
+    float ct[4] = {ct4[it].x, ct4[it].y, ct4[it].z, ct4[it].w};
     if (lr >= 0) {  // reset row (:199-203, :230-231)
       const int64_t i = g * GROUP + il;
       const u4 c{(uint32_t)i, (uint32_t)(j0 >> 2), (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};  // draws j0 .. j0+3
@@ -253,23 +282,21 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
       *reinterpret_cast<float4*>(a.r.dof_vel_out + row) =
           make_float4(0.2f * u01(x.x) + (-0.1f), 0.2f * u01(x.y) + (-0.1f), 0.2f * u01(x.z) + (-0.1f), 0.2f * u01(x.w) + (-0.1f));
 #pragma unroll
-      for (int q = 0; q < 4; ++q) ct[q] = p.default_dof_pos[j0 + q];
+      for (int q = 0; q < 4; ++q) ct[q] = s_def[j0 + q];
       *reinterpret_cast<float4*>(a.r.dof_pos_out + row) = make_float4(ct[0], ct[1], ct[2], ct[3]);
       ST4S(a.b.last_actions + base + e, make_float4(0.f, 0.f, 0.f, 0.f));
       ST4S(a.b.last_dof_vel + base + e, make_float4(0.f, 0.f, 0.f, 0.f));
-    } else {
-      const float4 t4 = LD4S(a.b.current_targets + base + e);
-      ct[0] = t4.x; ct[1] = t4.y; ct[2] = t4.z; ct[3] = t4.w;
     }
-    const float aa[4] = {av.x, av.y, av.z, av.w};
+    const float aa[4] = {v.x, v.y, v.z, v.w};
     float o[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)  // :190-193
-      o[q] = tensor_clamp(ct[q] + (p.action_scale * aa[q]) * p.dt, p.dof_lower[j0 + q], p.dof_upper[j0 + q]);
+      o[q] = tensor_clamp(ct[q] + (p.action_scale * aa[q]) * p.dt, s_lo[j0 + q], s_hi[j0 + q]);
     ST4S(a.b.current_targets + base + e, make_float4(o[0], o[1], o[2], o[3]));
   }
-  if (g == 0 && tid == 0) *a.r.count = (int64_t)group_offsets[G];
+  if (g == 0 && tid == 0) *a.r.count = (int64_t)total;
 }
+
 
 // reset_idx(env_ids) with caller-provided ids and (optionally) pre-drawn noise: one thread per id
 __global__ __launch_bounds__(256) void anymal_flat_reset_idx_kernel(const AnymalFlatPre a, int64_t max_ids) {
@@ -301,7 +328,8 @@ __global__ __launch_bounds__(256) void anymal_flat_reset_idx_kernel(const Anymal
     a.b.last_dof_vel[i * FD + j] = 0.0f;
   }
   const float u3[3] = {u[FD], u[FD + 1], u[FD + 2]};
-  anymal_flat_reset_head(a, i, k, u3);
+  const float ip[3] = {a.r.initial_root_pos[i * 3], a.r.initial_root_pos[i * 3 + 1], a.r.initial_root_pos[i * 3 + 2]};
+  anymal_flat_reset_head(a, i, k, u3, ip, *reinterpret_cast<const float4*>(a.r.initial_root_rot + i * 4));
 }
 
 static int check_flat(const oige_anymal_flat_params* p, const oige_anymal_flat_buffers* b, int64_t n, const char* who) {

@@ -176,11 +176,22 @@ __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a
   const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
   const bool flagged = live && a.b.reset_buf[env] != 0;  // :191
+  // the env's own target row and actions, fetched in front of every store of the kernel (r02: a load issued behind a store
+  // waits for that store's round trip; the r01 loop read and wrote the row element by element)
+  const int D = p.num_dof;
+  const int64_t le = live ? env : g * GROUP;
+  float tgv[BMAXD], ain[3];
+#pragma unroll
+  for (int j = 0; j < BMAXD; ++j) tgv[j] = j < D ? a.b.dof_position_targets[le * D + j] : 0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) ain[c] = a.actions_in[le * 3 + c];
+  const int32_t total = group_offsets[G];
   const int64_t k = group_rank(flagged, group_offsets, g, lds4);
   const int32_t k0 = group_offsets[g];
   const int cnt = group_offsets[g + 1] - k0;
   if (flagged) s_list[(int)(k - k0)] = tid;
   __syncthreads();
+  wait_loads_done();
   if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env
     const int64_t i = g * GROUP + s_list[tid];
     float u[5];
@@ -188,7 +199,6 @@ __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a
     ball_reset_env(a, i, (int64_t)k0 + tid, u);
   }
   if (live) {  // :196-204
-    const int D = p.num_dof;
     float* tg = a.b.dof_position_targets + env * D;
     if (flagged) {
       for (int j = 0; j < D; ++j) tg[j] = 0.0f;
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a
       for (int j = 0; j < BMAXD; ++j) add[j] = 0.0f;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        float av = a.actions_in[env * 3 + c];
+        float av = ain[c];
         if (a.flags & OIGE_PRE_CLAMP_ACTIONS) av = clamp_sym(av, p.clip_actions);
         const int j = p.actuated_dof_indices[c];
 #pragma unroll
@@ -208,13 +218,13 @@ __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a
       for (int j = 0; j < BMAXD; ++j) {
         if (j < D) {
           const bool act = j == p.actuated_dof_indices[0] || j == p.actuated_dof_indices[1] || j == p.actuated_dof_indices[2];
-          const float v = act ? tg[j] + add[j] : tg[j];
+          const float v = act ? tgv[j] + add[j] : tgv[j];
           tg[j] = tensor_clamp(v, p.dof_lower[j], p.dof_upper[j]);
         }
       }
     }
   }
-  if (g == 0 && tid == 0) *a.r.count = (int64_t)group_offsets[G];
+  if (g == 0 && tid == 0) *a.r.count = (int64_t)total;
 }
 
 __global__ __launch_bounds__(256) void ball_balance_reset_idx_kernel(const BallPre a, int64_t max_ids) {

@@ -989,6 +989,7 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
   if (tid < GROUP) s_rank[tid] = f_env ? (int)(kr - k0r) : -1;
   if (tid < A) s_inv[p.actuated_dof_indices[tid]] = tid;
   __syncthreads();
+  // (no wait_loads_done() here: measured 192 -> 198 us; the prev / cur target quads are not needed before phase 4)
 
   // ---- 2: dense resets.  Rows fetched first (the only loads left), then the draws, then the stores
   {

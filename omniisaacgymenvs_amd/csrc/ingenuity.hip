@@ -167,6 +167,13 @@ __global__ __launch_bounds__(GROUP) void ingenuity_pre_kernel(const IngPre a) {
   const bool live = env < a.n;
   const bool fr = live && a.b.reset_buf[env] != 0;
   const bool ft = live && (fr || a.b.progress_buf[env] % 500 == 0);
+  // the env's own rows, fetched in front of every store of the kernel (r02: a load issued behind a store waits for that
+  // store's round trip; reset envs read their actions too and ignore them)
+  const int64_t le = live ? env : g * GROUP;
+  const float2* ar = reinterpret_cast<const float2*>(a.actions_in + le * 6);
+  const float2 a0 = ar[0], a1 = ar[1], a2 = ar[2];
+  const float4 dv_in = *reinterpret_cast<const float4*>(a.b.dof_vel + le * 4);
+  const int32_t total_r = off_r[G], total_t = off_t[G];
   const int64_t kr = group_rank(fr, off_r, g, lds_a);
   const int64_t kt = group_rank(ft, off_t, g, lds_b);
   const int32_t k0r = off_r[g], k0t = off_t[g];
@@ -174,6 +181,7 @@ __global__ __launch_bounds__(GROUP) void ingenuity_pre_kernel(const IngPre a) {
   if (fr) s_list_r[(int)(kr - k0r)] = tid;
   if (ft) s_list_t[(int)(kt - k0t)] = tid;
   __syncthreads();
+  wait_loads_done();
   if (tid < cntr) {  // dense lanes: reset_idx
     const int64_t i = g * GROUP + s_list_r[tid];
     const u4 x = ing_block(a, i, 0u), y = ing_block(a, i, 1u);
@@ -190,8 +198,6 @@ __global__ __launch_bounds__(GROUP) void ingenuity_pre_kernel(const IngPre a) {
     float th[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!fr) {
       float av[6];
-      const float2* ar = reinterpret_cast<const float2*>(a.actions_in + env * 6);
-      const float2 a0 = ar[0], a1 = ar[1], a2 = ar[2];
       av[0] = a0.x; av[1] = a0.y; av[2] = a1.x; av[3] = a1.y; av[4] = a2.x; av[5] = a2.y;
       if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
 #pragma unroll
@@ -210,15 +216,15 @@ __global__ __launch_bounds__(GROUP) void ingenuity_pre_kernel(const IngPre a) {
     }
     float2* to = reinterpret_cast<float2*>(a.b.thrusts + env * 6);
     to[0] = make_float2(th[0], th[1]); to[1] = make_float2(th[2], th[3]); to[2] = make_float2(th[4], th[5]);
-    float4 dv = *reinterpret_cast<const float4*>(a.b.dof_vel + env * 4);
+    float4 dv = dv_in;
     if (fr) { dv.x = 0.f; dv.z = 0.f; }  // :230, then :178-179 for every env
     dv.y = 50.0f;
     dv.w = -50.0f;
     *reinterpret_cast<float4*>(a.b.dof_vel + env * 4) = dv;
   }
   if (g == 0 && tid == 0) {
-    *a.r.count = (int64_t)off_r[G];
-    *a.r.target_count = (int64_t)off_t[G];
+    *a.r.count = (int64_t)total_r;
+    *a.r.target_count = (int64_t)total_t;
   }
 }
 

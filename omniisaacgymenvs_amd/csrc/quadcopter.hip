@@ -119,13 +119,14 @@ __device__ __forceinline__ u4 quad_block(const QuadPre& a, int64_t i, uint32_t b
   return philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
 }
 
-// the root rows and flags of reset_idx (:209-227) for env i landing in compacted row k
-__device__ __forceinline__ void quad_reset_head(const QuadPre& a, int64_t i, int64_t k, const float (&u3)[3]) {
-  const float* ip = a.r.initial_root_pos + i * 3;
+// the root rows and flags of reset_idx (:209-227) for env i landing in compacted row k; ip / iq = initial_root_pos[i] /
+// initial_root_rot[i], fetched by the caller in front of its first store
+__device__ __forceinline__ void quad_reset_head(const QuadPre& a, int64_t i, int64_t k, const float (&u3)[3], const float (&ip)[3],
+                                                const float4 iq) {
   a.r.root_pos_out[k * 3 + 0] = ip[0] + (3.0f * u3[0] + (-1.5f));   // torch_rand_float(-1.5, 1.5)
   a.r.root_pos_out[k * 3 + 1] = ip[1] + (3.0f * u3[1] + (-1.5f));
   a.r.root_pos_out[k * 3 + 2] = ip[2] + (1.7f * u3[2] + (-0.2f));   // torch_rand_float(-0.2, 1.5)
-  *reinterpret_cast<float4*>(a.r.root_rot_out + k * 4) = *reinterpret_cast<const float4*>(a.r.initial_root_rot + i * 4);
+  *reinterpret_cast<float4*>(a.r.root_rot_out + k * 4) = iq;
 #pragma unroll
   for (int c = 0; c < 6; ++c) a.r.root_vel_out[k * 6 + c] = 0.0f;
   a.b.reset_buf[i] = 0;
@@ -137,9 +138,13 @@ __device__ __forceinline__ float4 quad_dof_draw(const u4 x) {  // torch_rand_flo
   return make_float4(0.4f * u01(x.x) + (-0.2f), 0.4f * u01(x.y) + (-0.2f), 0.4f * u01(x.z) + (-0.2f), 0.4f * u01(x.w) + (-0.2f));
 }
 
+// Order (r02): every load in front of the first store (target and action quads of the lane-linear walk, the env's thrusts and
+// thrust actions, then -- behind the ranks -- the dense lanes' initial rows); the DOF limit rows in LDS (indexed in place by a
+// run-time column they are vector loads of the argument block).  A load issued behind a store waits for that store's round trip.
 __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) {
   __shared__ int lds4[GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
+  __shared__ float s_lo[QD], s_hi[QD];
   const oige_quadcopter_params& p = a.p;
   const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
@@ -147,28 +152,58 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
   const int64_t G = num_groups(a.n);
   const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
+  const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
+  const int nf4 = (int)(envs_here * QD / 4);
+  // ---- loads
   const bool flagged = live && a.b.reset_buf[env] != 0;  // :147
-  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
   const int32_t k0 = group_offsets[g];
   const int cnt = group_offsets[g + 1] - k0;
+  const int32_t total = group_offsets[G];
+  float4 tq[QD / 4], aq[QD / 4];
+#pragma unroll
+  for (int it = 0; it < QD / 4; ++it) {
+    const int f = it * GROUP + tid;
+    const int e = 4 * (f < nf4 ? f : 0);  // idle lanes re-read the group's first quad
+    const int il = e / QD, j0 = e - il * QD;
+    const int64_t i = g * GROUP + il;
+    tq[it] = *reinterpret_cast<const float4*>(a.b.dof_position_targets + i * QD + j0);  // (reset rows read theirs too and ignore it)
+    aq[it] = *reinterpret_cast<const float4*>(a.actions_in + i * QA + j0);
+  }
+  const int64_t le = live ? env : g * GROUP;
+  const float4 th_in = *reinterpret_cast<const float4*>(a.b.thrusts + le * 4);
+  float4 ath = *reinterpret_cast<const float4*>(a.actions_in + le * QA + 8);
+  if (tid < QD) {
+    s_lo[tid] = p.dof_lower[tid];
+    s_hi[tid] = p.dof_upper[tid];
+  }
+  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
   __syncthreads();
-
-  if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env
-    const int64_t i = g * GROUP + s_list[tid];
-    const u4 x = quad_block(a, i, 2u);
-    const float u3[3] = {u01(x.x), u01(x.y), u01(x.z)};
-    quad_reset_head(a, i, (int64_t)k0 + tid, u3);
+  wait_loads_done();  // (in front of the dense lanes' block: inside it, waves without a dense lane would skip the wait)
+  const bool dense = tid < cnt;  // dense lanes: thread j takes the group's j-th flagged env
+  const int64_t di = g * GROUP + (dense ? s_list[tid] : 0);
+  float ip[3] = {0.f, 0.f, 0.f};
+  float4 iq = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (dense) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ip[c] = a.r.initial_root_pos[di * 3 + c];
+    iq = *reinterpret_cast<const float4*>(a.r.initial_root_rot + di * 4);
   }
 
-  const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
+  // ---- stores
+  if (dense) {
+    const u4 x = quad_block(a, di, 2u);
+    const float u3[3] = {u01(x.x), u01(x.y), u01(x.z)};
+    quad_reset_head(a, di, (int64_t)k0 + tid, u3, ip, iq);
+  }
+
   const float thrust_rate = p.thrust_rate;
   // DOF position targets: lane-linear over the group's 256 x 8 floats; the matching actions are columns 0:8 of a 12-wide row
 #pragma unroll
   for (int it = 0; it < QD / 4; ++it) {
     const int f = it * GROUP + tid;
-    if (f >= (int)(envs_here * QD / 4)) continue;
+    if (f >= nf4) continue;
     const int e = 4 * f;
     const int il = e / QD, j0 = e - il * QD;
     const int64_t i = g * GROUP + il;
@@ -180,16 +215,16 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
       *reinterpret_cast<float4*>(a.r.dof_pos_out + row) = out;
       *reinterpret_cast<float4*>(a.r.dof_vel_out + row) = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-      const float4 t4 = *reinterpret_cast<const float4*>(a.b.dof_position_targets + i * QD + j0);
-      float4 av = *reinterpret_cast<const float4*>(a.actions_in + i * QA + j0);
+      const float4 t4 = tq[it];
+      float4 av = aq[it];
       if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
         av.x = clamp_sym(av.x, p.clip_actions); av.y = clamp_sym(av.y, p.clip_actions);
         av.z = clamp_sym(av.z, p.clip_actions); av.w = clamp_sym(av.w, p.clip_actions);
       }
-      out.x = tensor_clamp(t4.x + p.dof_rate * av.x, p.dof_lower[j0 + 0], p.dof_upper[j0 + 0]);  // :154-157
-      out.y = tensor_clamp(t4.y + p.dof_rate * av.y, p.dof_lower[j0 + 1], p.dof_upper[j0 + 1]);
-      out.z = tensor_clamp(t4.z + p.dof_rate * av.z, p.dof_lower[j0 + 2], p.dof_upper[j0 + 2]);
-      out.w = tensor_clamp(t4.w + p.dof_rate * av.w, p.dof_lower[j0 + 3], p.dof_upper[j0 + 3]);
+      out.x = tensor_clamp(t4.x + p.dof_rate * av.x, s_lo[j0 + 0], s_hi[j0 + 0]);  // :154-157
+      out.y = tensor_clamp(t4.y + p.dof_rate * av.y, s_lo[j0 + 1], s_hi[j0 + 1]);
+      out.z = tensor_clamp(t4.z + p.dof_rate * av.z, s_lo[j0 + 2], s_hi[j0 + 2]);
+      out.w = tensor_clamp(t4.w + p.dof_rate * av.w, s_lo[j0 + 3], s_hi[j0 + 3]);
     }
     *reinterpret_cast<float4*>(a.b.dof_position_targets + i * QD + j0) = out;
   }
@@ -197,8 +232,8 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
   if (live) {
     float4 th = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!flagged) {
-      const float4 t4 = *reinterpret_cast<const float4*>(a.b.thrusts + env * 4);
-      float4 av = *reinterpret_cast<const float4*>(a.actions_in + env * QA + 8);
+      const float4 t4 = th_in;
+      float4 av = ath;
       if (a.flags & OIGE_PRE_CLAMP_ACTIONS) {
         av.x = clamp_sym(av.x, p.clip_actions); av.y = clamp_sym(av.y, p.clip_actions);
         av.z = clamp_sym(av.z, p.clip_actions); av.w = clamp_sym(av.w, p.clip_actions);
@@ -217,7 +252,7 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
       fz[2] = th.x; fz[5] = th.y; fz[8] = th.z; fz[11] = th.w;
     }
   }
-  if (g == 0 && tid == 0) *a.r.count = (int64_t)group_offsets[G];
+  if (g == 0 && tid == 0) *a.r.count = (int64_t)total;
 }
 
 // reset_idx(env_ids) with caller-provided ids and (optionally) pre-drawn U[0,1): one thread per id
@@ -243,7 +278,8 @@ __global__ __launch_bounds__(256) void quadcopter_reset_idx_kernel(const QuadPre
   float4* dv = reinterpret_cast<float4*>(a.r.dof_vel_out + k * QD);
   dp[0] = d0; dp[1] = d1;
   dv[0] = dv[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-  quad_reset_head(a, i, k, u3);
+  const float ip[3] = {a.r.initial_root_pos[i * 3], a.r.initial_root_pos[i * 3 + 1], a.r.initial_root_pos[i * 3 + 2]};
+  quad_reset_head(a, i, k, u3, ip, *reinterpret_cast<const float4*>(a.r.initial_root_rot + i * 4));
 }
 
 static int check_quad(const oige_quadcopter_params* p, const oige_quadcopter_buffers* b, int64_t n, const char* who) {

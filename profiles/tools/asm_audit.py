@@ -13,10 +13,15 @@ import glob, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 CSRC = os.path.join(ROOT, "omniisaacgymenvs_amd", "csrc")
-only = [a for a in sys.argv[1:] if not a.startswith("-D")]
+seq = None  # --seq=<substring of a kernel name>: print that kernel's memory-operation sequence instead of the table
+for a in sys.argv[1:]:
+    if a.startswith("--seq="):
+        seq = a[6:]
+only = [a for a in sys.argv[1:] if not a.startswith("-")]
 defines = [a for a in sys.argv[1:] if a.startswith("-D")]
 
-print(f"{'kernel':72s} {'loads':>6s} {'stores':>6s} {'ld>st':>6s} {'wait0>st':>8s}")
+if seq is None:
+    print(f"{'kernel':72s} {'loads':>6s} {'stores':>6s} {'ld>st':>6s} {'wait0>st':>8s}")
 with tempfile.TemporaryDirectory() as td:
     for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
         base = os.path.basename(src)[:-4]
@@ -27,10 +32,12 @@ with tempfile.TemporaryDirectory() as td:
                                "--cuda-device-only", "-S", "-I", os.path.join(ROOT, "include"), src, "-o", s] + defines,
                               stderr=subprocess.DEVNULL)
         name, seen_store, loads, stores, ld_after, wait_after = None, False, 0, 0, 0, 0
+        ops = []
         for line in open(s):
             m = re.match(r"^(_Z\w+):", line)
             if m:
                 name, seen_store, loads, stores, ld_after, wait_after = m.group(1), False, 0, 0, 0, 0
+                ops = []
                 continue
             if name is None:
                 continue
@@ -38,12 +45,22 @@ with tempfile.TemporaryDirectory() as td:
             if t.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")):
                 loads += 1
                 ld_after += seen_store
+                ops.append("L")
             elif t.startswith(("global_store", "buffer_store", "flat_store", "global_atomic")):
                 stores += 1
                 seen_store = True
-            elif t.startswith("s_waitcnt") and "vmcnt(0)" in t:
-                wait_after += seen_store
+                ops.append("S")
+            elif t.startswith("s_waitcnt") and "vmcnt(" in t:
+                wait_after += seen_store and "vmcnt(0)" in t
+                ops.append("w" + re.search(r"vmcnt\((\d+)\)", t).group(1))
+            elif t.startswith("s_barrier"):
+                ops.append("|")
+            elif "Loop Header" in t:
+                ops.append("{loop")
             elif t.startswith(".Lfunc_end"):
                 dn = subprocess.check_output(["c++filt", name], text=True).strip().replace("oige::", "")
-                print(f"{dn[:72]:72s} {loads:6d} {stores:6d} {ld_after:6d} {wait_after:8d}")
+                if seq is None:
+                    print(f"{dn[:72]:72s} {loads:6d} {stores:6d} {ld_after:6d} {wait_after:8d}")
+                elif seq in dn:
+                    print(dn + ":\n  " + " ".join(ops))
                 name = None
