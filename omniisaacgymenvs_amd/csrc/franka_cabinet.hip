@@ -238,6 +238,29 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
   const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
   const bool flagged = live && a.b.reset_buf[env] != 0;  // :364
+  // r02: the walk's action and target quads are fetched here, in front of every store of the kernel (a load issued behind a
+  // store waits for that store's round trip; r01 ran reset stores -> row stores -> these loads)
+  const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
+  const int total = (int)envs_here * FD;
+  const int64_t base = g * GROUP * FD;
+  constexpr int WIT = (GROUP * FD / 4 + GROUP - 1) / GROUP;
+  float avq[WIT][4], tvq[WIT][4];
+#pragma unroll
+  for (int it = 0; it < WIT; ++it) {
+    const int e = 4 * (it * GROUP + tid);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) avq[it][c] = tvq[it][c] = 0.f;
+    if (e + 3 < total) {
+      const float4 a4 = *reinterpret_cast<const float4*>(a.actions_in + base + e);
+      const float4 t4 = *reinterpret_cast<const float4*>(a.b.franka_dof_targets + base + e);
+      avq[it][0] = a4.x; avq[it][1] = a4.y; avq[it][2] = a4.z; avq[it][3] = a4.w;
+      tvq[it][0] = t4.x; tvq[it][1] = t4.y; tvq[it][2] = t4.z; tvq[it][3] = t4.w;
+    } else {
+      for (int c = 0; c < 4; ++c)
+        if (e + c < total) { avq[it][c] = a.actions_in[base + e + c]; tvq[it][c] = a.b.franka_dof_targets[base + e + c]; }
+    }
+  }
+  const int32_t total_resets = group_offsets[G];
   const int64_t k = group_rank(flagged, group_offsets, g, lds4);
   const int32_t k0 = group_offsets[g];
   const int cnt = group_offsets[g + 1] - k0;
@@ -251,6 +274,7 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
       s_rate[j] = p.dof_speed_scales[j] * p.dt;  // left to right: speed_scales * dt * actions * action_scale (:369)
     }
   __syncthreads();
+  wait_loads_done();  // (outside the dense lanes' block: inside it, waves without a dense lane would skip the wait)
 
   if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env
     const int il = s_list[tid];
@@ -273,25 +297,14 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
     }
   }
 
-  const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
-  const int total = (int)envs_here * FD;
-  const int64_t base = g * GROUP * FD;
   const bool clampa = a.flags & OIGE_PRE_CLAMP_ACTIONS;
 #pragma unroll
-  for (int it = 0; it < (GROUP * FD / 4 + GROUP - 1) / GROUP; ++it) {
+  for (int it = 0; it < WIT; ++it) {
     const int e = 4 * (it * GROUP + tid);
     if (e >= total) continue;
-    float av[4] = {0.f, 0.f, 0.f, 0.f}, tv[4] = {0.f, 0.f, 0.f, 0.f};
+    float (&av)[4] = avq[it];
+    float (&tv)[4] = tvq[it];
     const bool vec = e + 3 < total;
-    if (vec) {
-      const float4 a4 = *reinterpret_cast<const float4*>(a.actions_in + base + e);
-      const float4 t4 = *reinterpret_cast<const float4*>(a.b.franka_dof_targets + base + e);
-      av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
-      tv[0] = t4.x; tv[1] = t4.y; tv[2] = t4.z; tv[3] = t4.w;
-    } else {
-      for (int c = 0; c < 4; ++c)
-        if (e + c < total) { av[c] = a.actions_in[base + e + c]; tv[c] = a.b.franka_dof_targets[base + e + c]; }
-    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int ee = e + c;
@@ -310,8 +323,8 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
     }
   }
   if (g == 0 && tid == 0) {
-    *a.r.count = (int64_t)group_offsets[G];
-    *a.r.prop_count = (int64_t)group_offsets[G] * p.num_props;
+    *a.r.count = (int64_t)total_resets;
+    *a.r.prop_count = (int64_t)total_resets * p.num_props;
   }
 }
 
