@@ -137,10 +137,12 @@ def test_no_resets_leaves_consecutive_successes_unchanged():
 
 
 @pytest.mark.parametrize("cfg_name", ["ShadowHand", "ShadowHandOpenAI_FF"])
-@pytest.mark.parametrize("n,relative", [(64, False), (1000, False), (1000, True)])
-def test_sync_free_pre_physics_matches_oracle(cfg_name, n, relative):
+@pytest.mark.parametrize("n,relative,p_reset", [(64, False, 0.2), (1000, False, 0.2), (1000, True, 0.2),
+                                                (1000, False, 0.7),   # > 64 reset envs per 256-env group: the rows past the
+                                                (600, True, 1.0)])    # kernel's LDS staging (HAND_RMAX) take the per-lane path
+def test_sync_free_pre_physics_matches_oracle(cfg_name, n, relative, p_reset):
     env, task, st = _loaded(cfg_name, n, useRelativeControl=relative)
-    st["reset"] = (torch.rand(n, generator=torch.Generator().manual_seed(3)) < 0.2).long()
+    st["reset"] = (torch.rand(n, generator=torch.Generator().manual_seed(3)) < p_reset).long()
     st["reset_goal"] = (torch.rand(n, generator=torch.Generator().manual_seed(4)) < 0.3).long()
     workloads.load_hand_state(task, st)
     spec, b = _spec(task), _oracle_buffers(task)

@@ -101,8 +101,10 @@ def test_ant_step_clamps_actions_in_kernel(fused_io):
         assert obs_dict["obs"].data_ptr() != task.obs_buf.data_ptr()
 
 
-@pytest.mark.parametrize("cfg,n", [("ShadowHandOpenAI_FF", 600), ("ShadowHand", 257), ("ShadowHandOpenAI_FF", 4096)])
-def test_in_kernel_dr_noise_is_bit_identical_to_the_separate_launch(cfg, n):
+@pytest.mark.parametrize("cfg,n,all_reset", [("ShadowHandOpenAI_FF", 600, False), ("ShadowHand", 257, False),
+                                             ("ShadowHandOpenAI_FF", 4096, False),
+                                             ("ShadowHandOpenAI_FF", 700, True)])  # every env resets on the first step: the
+def test_in_kernel_dr_noise_is_bit_identical_to_the_separate_launch(cfg, n, all_reset):  # rows past the LDS staging
     """fused_dr (noise applied inside hand_pre / hand_post) against the oige_dr_noise_apply launches: same Philox keys,
     same arithmetic -> identical bits in everything the step leaves behind."""
     dr = copy.deepcopy(TASK_DEFAULTS[cfg]["domain_randomization"])
@@ -114,6 +116,8 @@ def test_in_kernel_dr_noise_is_bit_identical_to_the_separate_launch(cfg, n):
         env.fused_dr = fused_dr
         st = workloads.hand_state(n, task._env_pos.cpu(), task.goal_pos.cpu(), task.hand_dof_lower_limits.cpu(),
                                   task.hand_dof_upper_limits.cpu(), device="cpu", seed=7)
+        if all_reset:
+            st["reset"] = torch.ones_like(st["reset"])
         workloads.load_hand_state(task, st)
         for v in (task._hands, task._objects, task._goals):
             v.apply_resets = False
