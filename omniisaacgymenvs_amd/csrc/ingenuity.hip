@@ -77,6 +77,10 @@ __device__ __forceinline__ void ing_post_tile(const IngPost& a, float* __restric
     if (live) a.b.reset_buf[env] = r ? 1 : 0;
     const unsigned long long m = __ballot(live && r);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
+    // and of the second list the next pre_physics_step compacts (reset or progress % 500 == 0, :154-160), so that it can
+    // skip its counting launch (OIGE_PRE_COUNTS_VALID)
+    const unsigned long long mt = __ballot(live && (r || progress % 500 == 0));
+    if (a.b.target_workspace && lane == 0) a.b.target_workspace[t] = __popcll(mt);
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   __syncthreads();
@@ -345,8 +349,10 @@ int oige_ingenuity_pre_physics(const oige_ingenuity_params* params, const float*
   const int64_t G = num_groups(num_envs);
   if (G == 0) return OIGE_OK;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(ingenuity_count_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
-  if (int rc = check_launch("ingenuity_count_kernel")) return rc;
+  if (!(flags & OIGE_PRE_COUNTS_VALID)) {  // the post kernel's DONE stage leaves the same tile counts
+    hipLaunchKernelGGL(ingenuity_count_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    if (int rc = check_launch("ingenuity_count_kernel")) return rc;
+  }
   if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.target_workspace, s)) return rc;
   hipLaunchKernelGGL(ingenuity_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   return check_launch("ingenuity_pre_kernel");

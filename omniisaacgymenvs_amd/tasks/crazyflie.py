@@ -248,6 +248,7 @@ class CrazyflieTask(RLTask):
         rc = _lib.load().oige_crazyflie_pre_physics(C.byref(p), actions.data_ptr(), self.root_rot.data_ptr(), C.byref(b), C.byref(r),
                                                     n, flags, _lib.current_stream(self.obs_buf.device))
         _lib.check(rc, "oige_crazyflie_pre_physics")
+        self._counts_key = None  # the kernel cleared the flags of the envs it reset (raw-pointer writes: no version bump)
         if self.sync_free:
             self._bind_extras()  # holds the last reset's means; untouched on steps without a reset, as in the reference
             self._apply_reset_writes(None)

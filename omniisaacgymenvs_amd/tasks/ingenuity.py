@@ -134,6 +134,10 @@ class IngenuityTask(RLTask):
         rc = _lib.load().oige_ingenuity_post_physics(C.byref(p), C.byref(s), C.byref(b), self._num_envs, stages,
                                                      _lib.current_stream(self.obs_buf.device))
         _lib.check(rc, "oige_ingenuity_post_physics")
+        if stages & _lib.STAGE_DONE:  # the DONE stage leaves the tile counts of both lists pre_physics_step compacts
+            self._mark_counts(self.reset_buf, self.progress_buf)
+        elif stages & _lib.STAGE_PROGRESS:  # progress moved under the target list's counts (a raw-pointer write: no version bump)
+            self._counts_key = None
 
     # ------------------------------------------------------------------ RLTask methods
     def get_observations(self) -> dict:
@@ -209,6 +213,8 @@ class IngenuityTask(RLTask):
             if len(set_target_ids) > 0:
                 self.set_targets(set_target_ids)
             self.progress_buf_saved = None
+        elif self._counts_valid(self.reset_buf, self.progress_buf):
+            flags |= _lib.PRE_COUNTS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS
         if not self.sync_free:
@@ -219,6 +225,7 @@ class IngenuityTask(RLTask):
         rc = _lib.load().oige_ingenuity_pre_physics(C.byref(p), actions.data_ptr(), C.byref(b), C.byref(r), n, flags,
                                                     _lib.current_stream(self.obs_buf.device))
         _lib.check(rc, "oige_ingenuity_pre_physics")
+        self._counts_key = None  # the kernel cleared the flags of the envs it reset (raw-pointer writes: no version bump)
         if self.sync_free:
             self._apply_reset_writes(None)
             self._apply_target_writes(None)
