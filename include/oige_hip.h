@@ -169,7 +169,10 @@ typedef struct oige_locomotion_reset_io {
 } oige_locomotion_reset_io;
 
 #define OIGE_PRE_CLAMP_ACTIONS 1u /* fold VecEnvRLGames' torch.clamp(actions, +-clip) (vec_env_rlgames.py:77) */
-#define OIGE_PRE_COUNTS_VALID 2u  /* reset_workspace tile counts already match reset_buf (skip recount) */
+#define OIGE_PRE_COUNTS_VALID 2u  /* the workspaces' tile counts already match the flag buffers (skip the recount): true right
+                                   * after a *_post_physics call with OIGE_STAGE_DONE on the same buffers and nothing written
+                                   * to them since.  Ingenuity / Crazyflie: the DONE stage also leaves target_workspace's
+                                   * counts (reset | progress % 500 == 0), so progress_buf must be untouched as well. */
 
 /* get_dof_at_limit_cost() as the reference's public method returns it (tasks/ant.py:102-109: jit sum(obs[:, 12:12+D] > 0.99)
  * -> (N,) int64; tasks/humanoid.py:130-141: scaled, motor-effort-weighted excess over 0.98 -> (N,) fp32), from obs_buf.
