@@ -966,6 +966,13 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
   }
   const int32_t k0g = off_g[g], k0r = off_r[g];
   const int cntg = off_g[g + 1] - k0g, cntr = off_r[g + 1] - k0r;
+  // the per-step action noise of this thread's quads, drawn while the loads above are in flight (it depends on none of them)
+  float nsi[DR ? AIT : 1][4];
+  const bool draw_ahead = DR && a.dn.on_interval.enabled != 0;
+  if (draw_ahead) {
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) noise_interval_samples(a.dn, (base_a >> 2) + it * HPNT + tid, nsi[it]);
+  }
 
   // ---- 1: ranks and lists
   const bool f_env = f_env_raw != 0, f_goal = f_goal_raw != 0;
@@ -1081,7 +1088,8 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
           de &= ~1;
         }
         const int dec[4] = {de, de, de, de};
-        const bool dirty = noise_apply4(a.dn, dec, 4, (base_a >> 2) + f, vv, c);
+        const bool dirty = draw_ahead ? noise_apply4_drawn(a.dn, dec, 4, (base_a >> 2) + f, vv, c, nsi[it])
+                                      : noise_apply4(a.dn, dec, 4, (base_a >> 2) + f, vv, c);
         v = make_float4(vv[0], vv[1], vv[2], vv[3]);
         ST4S(a.dn.buffer + base_a + 4 * f, v);
         if (dirty) *reinterpret_cast<float4*>(a.dn.correlated_noise + base_a + 4 * f) = make_float4(c[0], c[1], c[2], c[3]);

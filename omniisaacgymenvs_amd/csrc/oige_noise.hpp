@@ -140,6 +140,40 @@ __device__ __forceinline__ void noise_apply4_refreshed(const oige_noise_args& a,
   }
 }
 
+// noise_apply4 with the uncorrelated ("interval") samples of the quad drawn AHEAD by noise_interval_samples: they depend on
+// nothing a kernel loads (key = seed, step, flat float4 index, stream), so a kernel can compute them between issuing its
+// loads and its first wait, where the Philox + Box-Muller arithmetic costs no time.  Same key, same arithmetic, same bits.
+__device__ __forceinline__ void noise_interval_samples(const oige_noise_args& a, int64_t gf, float (&si)[4]) {
+  const uint64_t step = step_of(a);
+  const u4 cc{(uint32_t)gf, (uint32_t)(gf >> 32) | ((uint32_t)(5 + 2 * a.stream_id) << 16), (uint32_t)step, (uint32_t)(step >> 32)};
+  noise_samples(a.on_interval, philox4x32_10(cc, (uint32_t)a.seed, (uint32_t)(a.seed >> 32)), si);
+}
+
+__device__ __forceinline__ bool noise_apply4_drawn(const oige_noise_args& a, const int (&dec)[4], int nvalid, int64_t gf, float (&v)[4],
+                                                   float (&c)[4], const float (&si)[4]) {
+  const bool has_reset = a.on_reset.enabled != 0;
+  const bool scale_r = a.on_reset.operation == OIGE_NOISE_SCALING, scale_i = a.on_interval.operation == OIGE_NOISE_SCALING;
+  bool have_r = false, dirty = false;
+  float sr[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k >= nvalid) continue;
+    if (has_reset) {
+      if (dec[k] & 1) {  // correlated_noise_buffer[reset_ids] = sample  (:379-400)
+        if (!have_r) {
+          noise_reset_samples(a, gf, sr);
+          have_r = true;
+        }
+        c[k] = sr[k];
+        dirty = true;
+      }
+      v[k] = scale_r ? v[k] * c[k] : v[k] + c[k];  // buffer (+|*)= correlated_noise_buffer, all envs (:404-407)
+    }
+    if (dec[k] & 2) v[k] = scale_i ? v[k] * si[k] : v[k] + si[k];  // buffer[randomize_ids] (+|*)= noise  (:365-368)
+  }
+  return dirty;
+}
+
 // what a fused kernel may be handed: Philox samples only, the buffer and width it expects
 inline int noise_validate_fused(const oige_noise_args* a, const void* buffer, int width, const char* who) {
   OIGE_REQUIRE(a->buffer == buffer && a->width == width, "%s: noise args must address the kernel's own (N,%d) buffer", who, width);
