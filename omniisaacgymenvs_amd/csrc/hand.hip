@@ -998,27 +998,32 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
   __syncthreads();
   // (no wait_loads_done() here: measured 192 -> 198 us; the prev / cur target quads are not needed before phase 4)
 
-  // ---- 2: dense resets.  Rows fetched first (the only loads left), then the draws, then the stores
+  // ---- 2: dense resets, spread over the workgroup's waves so that no wave carries more than one Philox-and-rotation job
+  // (all on the first wave they were 2100 issue slots in front of the barrier below): reset_idx's object rows and flags on
+  // lanes 0.., goal-only envs on lanes 64.., reset_idx's nested reset_target_pose on lanes 128.., the DOF-row / correlated
+  // noise re-draws from lane DOFF on.  Rows fetched first (the only loads left), then the draws, then the stores.
   {
-    const int tg = (tid + HPNT - WAVE) & (HPNT - 1);  // goal-only envs start on the second wave
-    const bool do_r = tid < cntr, do_g = tg < cntg;
-    const int il_r = do_r ? s_list_r[tid] : 0, il_g = do_g ? s_list_g[tg] : 0;
-    const int64_t ir = g * GROUP + il_r, ig = g * GROUP + il_g;
-    float gi_r[3] = {0.f, 0.f, 0.f}, ep_r[3] = {0.f, 0.f, 0.f}, oi_r[3] = {0.f, 0.f, 0.f};
+    constexpr int DOFF = HPNT >= 512 ? 256 : 192;
+    const int tg = (tid + HPNT - WAVE) & (HPNT - 1), trg = (tid + HPNT - 2 * WAVE) & (HPNT - 1), td = (tid + HPNT - DOFF) & (HPNT - 1);
+    static_assert((HPNT & (HPNT - 1)) == 0 && HPNT >= 256, "lane rotations assume a power-of-two workgroup of at least four waves");
+    const bool do_r = tid < cntr, do_g = tg < cntg, do_rg = trg < cntr;
+    const int il_r = do_r ? s_list_r[tid] : 0, il_g = do_g ? s_list_g[tg] : 0, il_rg = do_rg ? s_list_r[trg] : 0;
+    const int64_t ir = g * GROUP + il_r, ig = g * GROUP + il_g, irg = g * GROUP + il_rg;
+    float ep_r[3] = {0.f, 0.f, 0.f}, oi_r[3] = {0.f, 0.f, 0.f};
     float gi_g[3] = {0.f, 0.f, 0.f}, ep_g[3] = {0.f, 0.f, 0.f};
     if (do_r) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        gi_r[c] = a.r.goal_init_pos[ir * 3 + c];
         ep_r[c] = a.r.env_pos[ir * 3 + c];
         oi_r[c] = a.r.object_init_pos[ir * 3 + c];
       }
     }
-    if (do_g) {
+    if (do_g || do_rg) {  // (a lane is on at most one of the two lists unless the group holds more than 192 of either)
+      const int64_t ii = do_g ? ig : irg;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        gi_g[c] = a.r.goal_init_pos[ig * 3 + c];
-        ep_g[c] = a.r.env_pos[ig * 3 + c];
+        gi_g[c] = a.r.goal_init_pos[ii * 3 + c];
+        ep_g[c] = a.r.env_pos[ii * 3 + c];
       }
     }
     if (DR && live) a.dn.counter[env] = my_cnt;  // (behind every load of this thread)
@@ -1028,12 +1033,26 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
       hand_goal_write(a, ig, (int64_t)k0g + tg, u[0], u[1], gi_g, ep_g, s_rank[il_g] < 0, a.r.goal_world_pos_out, a.r.goal_rot_out);
       a.r.goal_ids[k0g + tg] = ig;
     }
-    if (do_r) {  // reset_idx (:397-441) without its DOF rows
+    if (do_rg) {  // reset_idx's reset_target_pose (:401)
+      float gi2[3], ep2[3];
+      if (do_g) {  // the lane also held a goal-only env: its rows belong to that one, fetch this env's
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          gi2[c] = a.r.goal_init_pos[irg * 3 + c];
+          ep2[c] = a.r.env_pos[irg * 3 + c];
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { gi2[c] = gi_g[c]; ep2[c] = ep_g[c]; }
+      }
+      float ug[4];
+      hand_draw<4>(a.r, irg, 2u, ug);
+      hand_goal_write(a, irg, (int64_t)k0r + trg, ug[0], ug[1], gi2, ep2, true, a.r.r_goal_world_pos_out, a.r.r_goal_rot_out);
+    }
+    if (do_r) {  // reset_idx (:397-441) without its DOF rows and its goal
       const int64_t k = (int64_t)k0r + tid;
-      float u[8], ug[4];
+      float u[8];
       hand_draw<8>(a.r, ir, 1u, u);  // draws 0..4 of the (n,53) table
-      hand_draw<4>(a.r, ir, 2u, ug);
-      hand_goal_write(a, ir, k, ug[0], ug[1], gi_r, ep_r, true, a.r.r_goal_world_pos_out, a.r.r_goal_rot_out);  // :401
 #pragma unroll
       for (int c = 0; c < 3; ++c) a.r.object_pos_out[k * 3 + c] = (oi_r[c] + p.reset_position_noise * u[c]) + ep_r[c];  // :404-406
       const q4 orot = randomize_rotation(u[3], u[4]);                                                             // :408-410
@@ -1048,7 +1067,7 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
     // DOF rows of the first HAND_RMAX reset envs, one float4 per lane, into LDS (their compacted rows leave in phase 6:
     // stores issued here would sit in front of phase 3's first use of the loaded actions)
     const int nr = cntr < HAND_RMAX ? cntr : HAND_RMAX;
-    for (int w = tid; w < nr * (D / 4); w += HPNT) {
+    for (int w = td; w < nr * (D / 4); w += HPNT) {
       const int r = w / (D / 4), j0 = 4 * (w - r * (D / 4));
       float pos[4], vel[4];
       hand_redraw_quad(a, tab, g * GROUP + s_list_r[r], D, j0, pos, vel);
@@ -1056,7 +1075,7 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
       *reinterpret_cast<float4*>(s_rvel + r * D + j0) = make_float4(vel[0], vel[1], vel[2], vel[3]);
     }
     if (DR && has_cor) {  // correlated_noise_buffer[reset_ids] = sample (randomize.py:379-400), same Philox key as noise_apply4
-      for (int w = tid; w < nr * (A / 4); w += HPNT) {
+      for (int w = td; w < nr * (A / 4); w += HPNT) {
         const int r = w / (A / 4), q = w - r * (A / 4);
         const int64_t gf = (base_a >> 2) + (int64_t)s_list_r[r] * (A / 4) + q;
         float sr[4];
