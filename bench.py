@@ -976,15 +976,20 @@ def main() -> None:
         e1.record()
         after()
 
+    # the copy calibration (a few dozen streaming copies of the post kernel's footprint) runs first: by the time the W
+    # warmup steps start the GPU is at its running clocks, which a 5-step warmup of 0.15 ms steps does not reach by itself
+    copy_gbs = measured_copy_gbs(dev, bench.post_bytes * n) if not dry else None
+    # first use of torch's reduction kernels (lazy code-object load) and of the communicator (RCCL sets its rings up
+    # lazily): keep both out of the timed region -- and IN FRONT of the warmup steps: the reduction's blocking read-backs
+    # leave the host core in a low-power state and the step's Python working set cold, and the first step after them costs
+    # 150-200 us more on the host (profiles/tools/dbg_first_step.py): 7 % of a 20-step run when it was the first timed step
+    t = bench.task
+    od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
     for _ in range(args.warmup):
         bench.pre()
         bench.post()
         after()
     sync()
-    # first use of torch's reduction kernels (lazy code-object load) and of the communicator (RCCL sets its rings up
-    # lazily): keep both out of the timed region
-    t = bench.task
-    od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
     if dist is not None:
         dist.barrier()
     sync()
@@ -995,18 +1000,27 @@ def main() -> None:
             bench.pre()
         ev_pairs[-1][1].record()
     else:
-        for es, (e0, e1) in zip(ev_start, ev_pairs):
-            timed_step(es, e0, e1)
-    # episode statistics [sum reward, n done, sum episode length of done envs, successes, n envs]: the path's only
-    # cross-rank exchange, one 40-byte all-reduce over RCCL (utils/distributed.py)
-    t = bench.task
-    job_stats = od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
+        if os.environ.get("OIGE_BENCH_DUMP_STEPS"):  # host-side time of each call of the first steps, to stderr
+            host = []
+            for es, (e0, e1) in zip(ev_start, ev_pairs):
+                h0 = time.perf_counter(); es.record(); h1 = time.perf_counter(); bench.pre(); h2 = time.perf_counter()
+                e0.record(); bench.post(); h3 = time.perf_counter(); e1.record(); after()
+                host.append(tuple(round((b - a) * 1e6, 1) for a, b in ((h0, h1), (h1, h2), (h2, h3))))
+            print("host us (record, pre, post):", host[:8], file=sys.stderr)
+        else:
+            for es, (e0, e1) in zip(ev_start, ev_pairs):
+                timed_step(es, e0, e1)
     sync()
     if dist is not None:
         dist.barrier()
     sync()
     timing = reduce_timing(dist, time.perf_counter() - t0, dev, backend)
     elapsed = timing["elapsed"]
+    # episode statistics [sum reward, n done, sum episode length of done envs, successes, n envs]: the path's only
+    # cross-rank exchange, one 40-byte all-reduce over RCCL (utils/distributed.py).  Once per run and not a step of the
+    # path, so outside the bracket that times EXACTLY K steps (r01 had it inside: 5 % of a 20-step run).
+    t = bench.task
+    job_stats = od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
 
     if dry:
         post_ms = pre_ms = gpu_span_ms = None
@@ -1017,6 +1031,12 @@ def main() -> None:
         pre_ms = sum(es.elapsed_time(e0) for es, (e0, _) in zip(ev_start, ev_pairs)) / len(ev_pairs)
     if not dry:
         gpu_span_ms = ev_start[0].elapsed_time(ev_pairs[-1][1]) / len(ev_pairs)  # first pre launch -> last post end, per step
+        if os.environ.get("OIGE_BENCH_DUMP_STEPS") and not args.graph:  # per-step (pre, post, gap to the next step) in us, to stderr
+            rows = []
+            for i, (es, (e0, e1)) in enumerate(zip(ev_start, ev_pairs)):
+                gap = e1.elapsed_time(ev_start[i + 1]) if i + 1 < len(ev_start) else 0.0
+                rows.append((round(es.elapsed_time(e0) * 1e3, 1), round(e0.elapsed_time(e1) * 1e3, 1), round(gap * 1e3, 1)))
+            print("steps (pre us, post us, gap us):", rows[:40], file=sys.stderr)
 
     # second leg (default line): the same K steps replayed as ONE HIP graph per step (RLTask.capture_step), so the line
     # shows what launch gaps and Python marshalling cost next to the eager figure.  Outside the timed region above.
@@ -1024,7 +1044,6 @@ def main() -> None:
     if not dry and not args.graph and not args.no_graph_leg:
         graph_ms, graph_note = graph_leg(bench, args.steps, dist)
 
-    copy_gbs = measured_copy_gbs(dev, bench.post_bytes * n) if rank == 0 and not dry else None
     traffic = None
     if args.traffic_json and os.path.exists(args.traffic_json) and not dry:
         with open(args.traffic_json) as f:
