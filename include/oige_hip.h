@@ -453,6 +453,10 @@ int oige_anymal_height_min(const int16_t* height_samples, int32_t hs_rows, int32
  * torques = clip(Kp*(action_scale*actions + default_dof_pos - dof_pos) - Kd*dof_vel, -80, 80)   */
 int oige_anymal_torques(const oige_anymal_params* params, const float* actions, const float* dof_pos,
                         const float* dof_vel, float* torques_out, int64_t num_envs, oige_stream_t stream);
+/* The same with `self.actions = actions.clone()` (:390) folded in: actions_out (N,12) receives the copy the rest of the
+ * step reads (the first decimation sub-step's launch; the following ones use oige_anymal_torques on the copy). */
+int oige_anymal_torques_clone(const oige_anymal_params* params, const float* actions, float* actions_out, const float* dof_pos,
+                              const float* dof_vel, float* torques_out, int64_t num_envs, oige_stream_t stream);
 
 /* post_physics_step (:409-444) in the reference's order: progress += 1; body-frame velocities,
  * projected gravity, heading command (:421-427); check_termination (:452-466); calculate_metrics

@@ -427,6 +427,7 @@ SIGNATURES = {
     "oige_dr_noise_apply": (C.c_int, [C.POINTER(NoiseArgs), C.c_int64, _P]),
     "oige_anymal_height_min": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "oige_anymal_torques": (C.c_int, [C.POINTER(AnymalParams), _P, _P, _P, _P, C.c_int64, _P]),
+    "oige_anymal_torques_clone": (C.c_int, [C.POINTER(AnymalParams), _P, _P, _P, _P, _P, C.c_int64, _P]),
     "oige_anymal_post_physics": (C.c_int, [C.POINTER(AnymalParams), C.POINTER(AnymalState), C.POINTER(AnymalBuffers),
                                            C.POINTER(AnymalResetIO), C.c_int64, _P]),
     "oige_anymal_reset_idx": (C.c_int, [C.POINTER(AnymalParams), C.POINTER(AnymalState), C.POINTER(AnymalBuffers),

@@ -63,25 +63,30 @@ __global__ __launch_bounds__(256) void anymal_height_min_kernel(const int16_t* _
 }
 
 // ------------------------------------------------------------------ PD torques (:398-403)
+// actions_out (optional): `self.actions = actions.clone()` (:390) folded into the first sub-step's launch
 __global__ __launch_bounds__(256) void anymal_torques_kernel(const oige_anymal_params p, const float* __restrict__ actions,
                                                              const float* __restrict__ dof_pos,
                                                              const float* __restrict__ dof_vel,
-                                                             float* __restrict__ torques, int64_t total) {
+                                                             float* __restrict__ torques, float* __restrict__ actions_out,
+                                                             int64_t total) {
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t e = 4 * f;  // total = N*12 is a multiple of 4 and a float4 never straddles a row
   if (e >= total) return;
   const float4 a = *reinterpret_cast<const float4*>(actions + e);
   const float4 q = *reinterpret_cast<const float4*>(dof_pos + e);
   const float4 v = *reinterpret_cast<const float4*>(dof_vel + e);
-  const int c0 = (int)(e % AD);
+  const int g3 = (int)(f % 3);  // which third of the 12-wide row; the defaults picked from compile-time indices (a run-time
+                                // index into the argument block is a vector load per element)
   const float av[4] = {a.x, a.y, a.z, a.w}, qv[4] = {q.x, q.y, q.z, q.w}, vv[4] = {v.x, v.y, v.z, v.w};
   float o[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const float t = p.Kp * ((p.action_scale * av[k] + p.default_dof_pos[c0 + k]) - qv[k]) - p.Kd * vv[k];
+    const float d = g3 == 0 ? p.default_dof_pos[k] : (g3 == 1 ? p.default_dof_pos[4 + k] : p.default_dof_pos[8 + k]);
+    const float t = p.Kp * ((p.action_scale * av[k] + d) - qv[k]) - p.Kd * vv[k];
     o[k] = (t != t) ? t : (t < -80.0f ? -80.0f : (t > 80.0f ? 80.0f : t));
   }
   *reinterpret_cast<float4*>(torques + e) = make_float4(o[0], o[1], o[2], o[3]);
+  if (actions_out) *reinterpret_cast<float4*>(actions_out + e) = a;
 }
 
 // ------------------------------------------------------------------ flags (:410, :452-466)
@@ -849,18 +854,30 @@ int oige_anymal_height_min(const int16_t* height_samples, int32_t hs_rows, int32
   return check_launch("anymal_height_min_kernel");
 }
 
-int oige_anymal_torques(const oige_anymal_params* params, const float* actions, const float* dof_pos,
-                        const float* dof_vel, float* torques_out, int64_t num_envs, oige_stream_t stream) {
+static int anymal_torques(const oige_anymal_params* params, const float* actions, float* actions_out, const float* dof_pos,
+                          const float* dof_vel, float* torques_out, int64_t num_envs, oige_stream_t stream) {
   OIGE_REQUIRE(params && actions && dof_pos && dof_vel && torques_out, "anymal_torques: null pointer");
   OIGE_REQUIRE(num_envs >= 0 && num_envs < ((int64_t)1 << 31) / 256, "anymal_torques: num_envs %lld out of range", (long long)num_envs);
-  OIGE_REQUIRE(aligned16(actions) && aligned16(dof_pos) && aligned16(dof_vel) && aligned16(torques_out),
+  OIGE_REQUIRE(aligned16(actions) && aligned16(dof_pos) && aligned16(dof_vel) && aligned16(torques_out) && aligned16(actions_out),
                "anymal_torques: buffers must be 16-byte aligned");
+  OIGE_REQUIRE(actions_out != actions, "anymal_torques: actions_out must not alias actions");
   const int64_t total = num_envs * AD;
   if (total == 0) return OIGE_OK;
   const int64_t f4 = total / 4;
   hipLaunchKernelGGL(anymal_torques_kernel, dim3((unsigned)((f4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *params,
-                     actions, dof_pos, dof_vel, torques_out, total);
+                     actions, dof_pos, dof_vel, torques_out, actions_out, total);
   return check_launch("anymal_torques_kernel");
+}
+
+int oige_anymal_torques(const oige_anymal_params* params, const float* actions, const float* dof_pos,
+                        const float* dof_vel, float* torques_out, int64_t num_envs, oige_stream_t stream) {
+  return anymal_torques(params, actions, nullptr, dof_pos, dof_vel, torques_out, num_envs, stream);
+}
+
+int oige_anymal_torques_clone(const oige_anymal_params* params, const float* actions, float* actions_out, const float* dof_pos,
+                              const float* dof_vel, float* torques_out, int64_t num_envs, oige_stream_t stream) {
+  OIGE_REQUIRE(actions_out != nullptr, "anymal_torques_clone: null actions_out");
+  return anymal_torques(params, actions, actions_out, dof_pos, dof_vel, torques_out, num_envs, stream);
 }
 
 static int anymal_launch(const oige_anymal_params* params, const oige_anymal_state* state,

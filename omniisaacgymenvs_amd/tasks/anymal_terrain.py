@@ -418,20 +418,29 @@ class AnymalTerrainTask(RLTask):
         if not self.world.is_playing():
             return
         n = self._num_envs
-        self.actions = actions.clone().to(self.device)
-        _lib.require_device_tensor(self.actions, torch.float32, (n, 12), "actions")
+        actions = actions.to(self.device)
+        _lib.require_device_tensor(actions, torch.float32, (n, 12), "actions")
+        self.actions = torch.empty_like(actions)  # actions.clone() (:390): written by the first sub-step's launch
+        cloned = False
         p = self._params()
         lib, stream = _lib.load(), _lib.current_stream(self.obs_buf.device)
         for i in range(self.decimation):
             if self.world.is_playing():
                 torques = torch.empty_like(self.torques)
-                rc = lib.oige_anymal_torques(C.byref(p), self.actions.data_ptr(), self.dof_pos.data_ptr(),
-                                             self.dof_vel.data_ptr(), torques.data_ptr(), n, stream)
+                if not cloned:
+                    rc = lib.oige_anymal_torques_clone(C.byref(p), actions.data_ptr(), self.actions.data_ptr(), self.dof_pos.data_ptr(),
+                                                       self.dof_vel.data_ptr(), torques.data_ptr(), n, stream)
+                    cloned = True
+                else:
+                    rc = lib.oige_anymal_torques(C.byref(p), self.actions.data_ptr(), self.dof_pos.data_ptr(),
+                                                 self.dof_vel.data_ptr(), torques.data_ptr(), n, stream)
                 _lib.check(rc, "oige_anymal_torques")
                 self._anymals.set_joint_efforts(torques)
                 self.torques = torques
                 self.world.step(render=False)  # SimulationContext.step(self.world, render=False)
                 self.refresh_dof_state_tensors()
+        if not cloned:  # decimation 0 or the world stopped inside the loop: no launch took the copy
+            self.actions.copy_(actions)
 
     def post_physics_step(self, noise_u=None):
         if not self.world.is_playing():
