@@ -1117,6 +1117,8 @@ typedef struct oige_newhand_cabinet_buffers {
   float* keypoints_drawer;   /* (N,5,3) or NULL */
   int64_t* terminate_buf;    /* (N,) with terminate_on_limits: read by the reward (the PREVIOUS is_done's flags), rewritten by is_done */
   int32_t* reset_workspace;  /* as oige_locomotion_buffers.reset_workspace */
+  float* actuated_targets_out; /* (N,A) or NULL: pre_physics also writes dof_targets[:, actuated_dof_indices], the block the Tendon
+                                * task hands to set_joint_position_targets(joint_indices=...) (tomodj_newhandTendon_cabinet.py) */
 } oige_newhand_cabinet_buffers;
 
 /* post_physics_step: progress += 1, get_observations, calculate_metrics (compute_*_reward), is_done.  `stages` as for locomotion. */

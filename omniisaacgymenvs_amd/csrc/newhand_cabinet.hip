@@ -391,6 +391,7 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   __syncthreads();  // the reset envs' new rows and the group's actions are visible to the whole workgroup
 
   // ---- 4: targets: joint j integrates action column s_inv[j] (none: unchanged)
+  const bool want_act = a.b.actuated_targets_out != nullptr;  // dof_targets[:, actuated_dof_indices] as a second output
 #pragma unroll
   for (int it = 0; it < TIT; ++it) {
     const int e = 4 * (it * GROUP + tid);
@@ -406,12 +407,28 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
       const int ja = s_inv[jj];
       if (ja < 0) continue;
       tv[it][c] = tensor_clamp(tv[it][c] + (s_rate[jj] * s_act[il * A + ja]) * p.action_scale, s_lo[jj], s_hi[jj]);
+      if (want_act) s_act[il * A + ja] = tv[it][c];  // the action slot becomes the target slot (this thread alone touches it)
     }
     if (e + 3 < ttotal) {
       ST4S(a.b.dof_targets + tbase + e, make_float4(tv[it][0], tv[it][1], tv[it][2], tv[it][3]));
     } else {
       for (int c = 0; c < 4; ++c)
         if (e + c < ttotal) a.b.dof_targets[tbase + e + c] = tv[it][c];
+    }
+  }
+
+  if (want_act) {  // ---- 4b: the (N,A) block of actuated targets, lane-linear out of the LDS tile
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < AIT; ++it) {
+      const int e = 4 * (it * GROUP + tid);
+      if (e >= atotal) continue;
+      if (e + 3 < atotal) {
+        ST4S(a.b.actuated_targets_out + abase + e, *reinterpret_cast<const float4*>(s_act + e));
+      } else {
+        for (int c = 0; c < 4; ++c)
+          if (e + c < atotal) a.b.actuated_targets_out[abase + e + c] = s_act[e + c];
+      }
     }
   }
 

@@ -224,6 +224,10 @@ class _NewhandCabinetTask(RLTask):
         b.actions, b.dof_targets = self.actions.data_ptr(), self.robot_dof_targets.data_ptr()
         b.keypoints_finger, b.keypoints_drawer = self.keypoints_finger.data_ptr(), self.keypoints_drawer.data_ptr()
         b.terminate_buf, b.reset_workspace = self.terminate_buf.data_ptr(), self._reset_workspace.data_ptr()
+        if self.ACTUATED is not None:  # Tendon: robot_dof_targets[:, actuated_dof_indices] comes out of the pre kernel
+            if getattr(self, "_actuated_targets", None) is None:
+                self._actuated_targets = torch.zeros(n, self.num_actions, dtype=torch.float32, device=self._device)
+            b.actuated_targets_out = self._actuated_targets.data_ptr()
         return b
 
     def _state(self) -> _lib.NewhandCabinetState:
@@ -337,8 +341,7 @@ class _NewhandCabinetTask(RLTask):
             self._robots.set_joint_position_targets(self.robot_dof_targets)
         else:  # Tendon: only the actuated joints' targets are handed over (joint_indices=...)
             # (a Python list as index would be turned into a device tensor on every call: keep one)
-            self._robots.set_joint_position_targets(self.robot_dof_targets.index_select(1, self._actuated_index),
-                                                    joint_indices=self.actuated_dof_indices)
+            self._robots.set_joint_position_targets(self._actuated_targets, joint_indices=self.actuated_dof_indices)
 
     def reset_idx(self, env_ids):
         num = len(env_ids)

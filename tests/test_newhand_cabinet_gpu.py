@@ -118,6 +118,7 @@ def test_sync_free_pre_physics_matches_oracle(n, clamp, name):
         assert_equal(task.robot_dof_targets[:, passive][keep], st["targets"][:, passive][keep], "passive joints' targets untouched")
         vals, jidx = task._robots.joint_position_targets_subset
         assert list(jidx) == spec.actuated_dof_indices and vals.shape == (n, A)
+        assert_equal(vals, task.robot_dof_targets[:, spec.actuated_dof_indices], "the pre kernel's (N,A) block == dof_targets[:, actuated]")
     if rows is not None:
         dp = o["dof_pos"][:k].cpu()
         assert bool(((dp >= lo) & (dp <= hi)).all())
