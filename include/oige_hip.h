@@ -173,6 +173,9 @@ typedef struct oige_locomotion_reset_io {
                                    * after a *_post_physics call with OIGE_STAGE_DONE on the same buffers and nothing written
                                    * to them since.  Ingenuity / Crazyflie: the DONE stage also leaves target_workspace's
                                    * counts (reset | progress % 500 == 0), so progress_buf must be untouched as well. */
+#define OIGE_PRE_OFFSETS_VALID 4u /* in-hand tasks: the group offsets are valid too (oige_hand_post_physics[_dr] with
+                                   * OIGE_STAGE_METRICS scans both workspaces in its last launch): implies COUNTS_VALID,
+                                   * same condition; pre_physics then starts at its kernel */
 
 /* get_dof_at_limit_cost() as the reference's public method returns it (tasks/ant.py:102-109: jit sum(obs[:, 12:12+D] > 0.99)
  * -> (N,) int64; tasks/humanoid.py:130-141: scaled, motor-effort-weighted excess over 0.98 -> (N,) fp32), from obs_buf.

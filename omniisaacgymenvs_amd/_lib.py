@@ -18,7 +18,7 @@ OIGE_MAX_DOF = 32
 TILE_ENVS = 64
 
 STAGE_PROGRESS, STAGE_OBS, STAGE_METRICS, STAGE_DONE, STAGE_ALL = 1, 2, 4, 8, 15
-PRE_CLAMP_ACTIONS, PRE_COUNTS_VALID = 1, 2
+PRE_CLAMP_ACTIONS, PRE_COUNTS_VALID, PRE_OFFSETS_VALID = 1, 2, 4
 
 _f = C.c_float
 _fp = C.c_void_p  # device pointers travel as integers

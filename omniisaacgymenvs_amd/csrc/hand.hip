@@ -21,6 +21,7 @@
 #include "oige_common.hpp"
 #include "oige_math.hpp"
 #include "oige_noise.hpp"
+#include "oige_scan.hpp"
 #include "oige_tile.hpp"
 
 // lane-linear whole-line streams outside the tile helpers (noise epilogue / prologue, target walk)
@@ -685,9 +686,20 @@ __global__ __launch_bounds__(WAVE) void allegro_post_kernel(const HandPost a) {
     allegro_post_tile<OBS, false>(a, tile, t, (int)left);
 }
 
-// consecutive_successes update (:522-529): single workgroup, tile order
+// consecutive_successes update (:522-529): single workgroup, tile order.  Workgroups 1 and 2 of the same launch run the
+// group scans of the two compaction workspaces the post kernel just filled (the next pre_physics_step then starts at its
+// kernel: OIGE_PRE_OFFSETS_VALID): three one-workgroup, latency-bound passes side by side instead of two launches.
 __global__ __launch_bounds__(1024) void hand_finalize_kernel(const float* __restrict__ partials, int64_t tiles,
-                                                             float* __restrict__ cons, float av, float one_minus_av) {
+                                                             float* __restrict__ cons, float av, float one_minus_av,
+                                                             int32_t* __restrict__ ws_a, int32_t* __restrict__ ws_b,
+                                                             int64_t n_groups, int64_t padded) {
+  static_assert(SCAN_THREADS == 1024, "the scan workgroups share this launch's block size");
+  if (blockIdx.x > 0) {
+    __shared__ int wave_tot[SCAN_THREADS / WAVE];
+    int32_t* ws = blockIdx.x == 1 ? ws_a : ws_b;
+    scan_groups_body(ws, n_groups, tiles, ws + padded, wave_tot);
+    return;
+  }
   __shared__ double s_n[1024 / WAVE], s_f[1024 / WAVE];
   double n = 0.0, f = 0.0;
 #pragma unroll 8
@@ -1264,8 +1276,10 @@ static int launch_hand_post(const HandPost& a, hipStream_t s) {
 static int finalize_hand(const HandPost& a, hipStream_t s) {
   if (!(a.stages & OIGE_STAGE_METRICS)) return OIGE_OK;
   const float av = a.p.av_factor;  // reaches the jit function as float(fp32 tensor) (:59,:293)
-  hipLaunchKernelGGL(hand_finalize_kernel, dim3(1), dim3(1024), 0, s, a.b.reduce_workspace, num_tiles(a.n),
-                     a.b.consecutive_successes, av, (float)(1.0 - (double)av));
+  const bool scans = a.b.reset_workspace && a.b.goal_workspace;
+  hipLaunchKernelGGL(hand_finalize_kernel, dim3(scans ? 3 : 1), dim3(1024), 0, s, a.b.reduce_workspace, num_tiles(a.n),
+                     a.b.consecutive_successes, av, (float)(1.0 - (double)av), a.b.reset_workspace, a.b.goal_workspace,
+                     num_groups(a.n), padded_tiles(a.n));
   return check_launch("hand_finalize_kernel");
 }
 
@@ -1415,7 +1429,8 @@ static int hand_pre_physics(const oige_hand_params* params, const float* actions
     if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
     if (int rc = launch_count_flags(a.b.reset_goal_buf, num_envs, a.b.goal_workspace, s)) return rc;
   }
-  if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.goal_workspace, s)) return rc;
+  if ((flags & (OIGE_PRE_OFFSETS_VALID | OIGE_PRE_COUNTS_VALID)) != (OIGE_PRE_OFFSETS_VALID | OIGE_PRE_COUNTS_VALID))  // (both set: the post launch sequence already ran the scans, hand_finalize_kernel)
+    if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.goal_workspace, s)) return rc;
   const dim3 grid((unsigned)G);
   if (is_allegro(params)) {
     if (a.dr) hipLaunchKernelGGL((hand_pre_kernel<OIGE_ALLEGRO_DOFS, OIGE_ALLEGRO_DOFS, true, GROUP>), grid, dim3(GROUP), 0, s, a);

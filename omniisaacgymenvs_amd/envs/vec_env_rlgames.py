@@ -20,11 +20,13 @@ changing a value the policy sees:
 """
 from __future__ import annotations
 
+import gc
 import math
 from datetime import datetime
 
 import torch
 
+from ..tasks.base.rl_task import quiesce_gc
 from .vec_env_base import VecEnvBase
 
 
@@ -158,6 +160,7 @@ class VecEnvRLGames(VecEnvBase):
         t._capturing = True
         if dr is not None:
             dr.capturing = True
+        gc_on = quiesce_gc()
         try:
             with torch.cuda.stream(side):
                 t._step_dev += 1
@@ -178,6 +181,8 @@ class VecEnvRLGames(VecEnvBase):
             t._capturing = False
             if dr is not None:
                 dr.capturing = False
+            if gc_on:
+                gc.enable()
         self._graph, self._graph_out, self._graph_actions = graph, out, actions
 
     def replay_step(self):

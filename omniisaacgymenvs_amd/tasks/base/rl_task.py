@@ -10,6 +10,7 @@ env origins out on the same square grid the cloner would use.
 """
 from __future__ import annotations
 
+import gc
 import math
 from typing import Optional
 
@@ -18,6 +19,19 @@ import torch
 
 from ...utils.domain_randomization.randomize import Randomizer
 from ...utils.spaces import Box
+
+
+def quiesce_gc() -> bool:
+    """Collect now and switch the cyclic collector off; returns whether it was on (the caller switches it back on).
+
+    torch.cuda.graph() no longer collects on entry (torch >= 2.6: ``force_cudagraph_gc`` is off), and a collection that
+    starts inside a stream capture may drop an older ``CUDAGraph`` that sat in a reference cycle: its destructor calls
+    ``hipGraphExecDestroy`` while the capture is open, which HIP rejects, and an error in a destructor ends the process
+    (SIGABRT, seen once per some hundred captures when several tasks were captured in one process)."""
+    on = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    return on
 
 
 class RLTask:
@@ -171,6 +185,7 @@ class RLTask:
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         self._capturing = True
+        gc_on = quiesce_gc()
         try:
             with torch.cuda.stream(side):  # warm-up: one real step on the side stream
                 self._step_dev += 1
@@ -191,6 +206,8 @@ class RLTask:
             self._step_count = count0  # the captured step has not run yet
         finally:
             self._capturing = False
+            if gc_on:
+                gc.enable()
         self._graph, self._graph_post, self._graph_actions = graph, graph_post, actions
 
     def replay_step(self):

@@ -255,7 +255,11 @@ class InHandManipulationTask(RLTask):
         self._after_metrics()
 
     def _after_metrics(self):
-        self.extras["consecutive_successes"] = self.consecutive_successes.mean()
+        # :284 `self.consecutive_successes.mean()`: the mean of the (1,) tensor is that element; a 0-dim view of it instead of a
+        # 5 us reduction launch per step (the value is rewritten in place by the next step's finalize kernel, like the
+        # episode extras of the other tasks)
+        cs = self.consecutive_successes
+        self.extras["consecutive_successes"] = cs.reshape(()) if cs.numel() == 1 else cs.mean()
         if not self._dr_randomizer.randomize:
             pass  # randomization_buf only feeds the delegated PhysX DR; advanced in-kernel when DR is on
         if self.print_success_stat:
@@ -354,8 +358,8 @@ class InHandManipulationTask(RLTask):
             if ne > 0:
                 self.reset_idx(env_ids)
         else:
-            if self._counts_valid(self.reset_buf, self.reset_goal_buf):
-                flags |= _lib.PRE_COUNTS_VALID
+            if self._counts_valid(self.reset_buf, self.reset_goal_buf):  # (and the group scans: the post launch's last kernel)
+                flags |= _lib.PRE_COUNTS_VALID | _lib.PRE_OFFSETS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS  # the wrapper's clamp (vec_env_rlgames.py:77), folded into the kernel
         p, b, r = self._params(), self._buffers(), self._reset_io()
