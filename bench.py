@@ -52,6 +52,32 @@ def _pick(n, frac, dev, seed):
     return torch.rand(n, device=dev, generator=g) < frac
 
 
+def _steady_hand_state(st, t, n, frac, dev, seed):
+    """--reset-frac for the in-hand tasks: `frac` of the objects beyond fall_dist, as many at the goal rotation; no stale flags."""
+    far, hit = _pick(n, frac, dev, seed), _pick(n, frac, dev, seed + 1)
+    off = st["object_pos"] - (t.goal_pos + t._env_pos)
+    off = off * (0.15 / off.norm(dim=-1, keepdim=True).clamp(min=0.15))          # everyone within 0.15 m ...
+    off = torch.where(far.unsqueeze(-1), off * (0.3 / 0.15), off)                  # ... but these, at 0.3 m (fall_dist 0.24)
+    st["object_pos"] = (t.goal_pos + t._env_pos + off).contiguous()
+    q = torch.randn(n, 4, device=dev)
+    q = q / q.norm(dim=-1, keepdim=True)
+    st["object_rot"] = torch.where(hit.unsqueeze(-1), st["goal_rot"], q).contiguous()
+    st["reset"].zero_()
+    st["reset_goal"].zero_()
+    st["successes"].zero_()
+
+
+def _steady_cabinet_state(st, n, frac, dev, seed, open_at):
+    """--reset-frac for the cabinet tasks: the drawer joint below its done threshold `open_at` except for `frac` of the envs;
+    no stale flags.  The 500-step timeouts stay (progress is uniform over the episode: one env in 500 times out per step)."""
+    bad = _pick(n, frac, dev, seed)
+    d = st["cabinet_dof_pos"]
+    d[:, 3] = torch.where(bad, torch.full_like(d[:, 3], open_at + 0.03), d[:, 3].clamp(max=open_at - 0.02))
+    st["reset"].zero_()
+    if "terminate" in st:
+        st["terminate"].zero_()
+
+
 class LocomotionBench:
     def __init__(self, name, n, dev, seed, reset_frac=None):
         from omniisaacgymenvs_amd.utils.task_util import make_task
@@ -127,18 +153,8 @@ class HandBench:
         self.env, self.task = make_task("ShadowHandOpenAI_FF", n, device=dev, seed=seed, domain_randomization=dr)
         t = self.task
         st = workloads.hand_state(n, t._env_pos, t.goal_pos, t.hand_dof_lower_limits, t.hand_dof_upper_limits, device=dev, seed=seed)
-        if reset_frac is not None:  # `reset_frac` of the objects beyond fall_dist, as many at the goal rotation; no stale flags
-            far, hit = _pick(n, reset_frac, dev, seed), _pick(n, reset_frac, dev, seed + 1)
-            off = st["object_pos"] - (t.goal_pos + t._env_pos)
-            off = off * (0.15 / off.norm(dim=-1, keepdim=True).clamp(min=0.15))          # everyone within 0.15 m ...
-            off = torch.where(far.unsqueeze(-1), off * (0.3 / 0.15), off)                  # ... but these, at 0.3 m (fall_dist 0.24)
-            st["object_pos"] = (t.goal_pos + t._env_pos + off).contiguous()
-            q = torch.randn(n, 4, device=dev)
-            q = q / q.norm(dim=-1, keepdim=True)
-            st["object_rot"] = torch.where(hit.unsqueeze(-1), st["goal_rot"], q).contiguous()
-            st["reset"].zero_()
-            st["reset_goal"].zero_()
-            st["successes"].zero_()
+        if reset_frac is not None:
+            _steady_hand_state(st, t, n, reset_frac, dev, seed)
         workloads.load_hand_state(t, st)
         for v in (t._hands, t._objects, t._goals):
             v.apply_resets = False
@@ -305,8 +321,6 @@ class AllegroHandBench:
     """AllegroHand, `full` obs(72) + goal-rotation reward + resets (the YAML has no DR section)."""
 
     def __init__(self, name, n, dev, seed, reset_frac=None):
-        if reset_frac is not None:
-            raise SystemExit("--reset-frac is not defined for this task (see the adapters that take it)")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -314,6 +328,8 @@ class AllegroHandBench:
         t = self.task
         st = workloads.hand_state(n, t._env_pos, t.goal_pos, t.hand_dof_lower_limits, t.hand_dof_upper_limits, device=dev, seed=seed,
                                   num_actions=16, fingertips=0)
+        if reset_frac is not None:
+            _steady_hand_state(st, t, n, reset_frac, dev, seed)
         workloads.load_hand_state(t, st)
         for v in (t._hands, t._objects, t._goals):
             v.apply_resets = False
@@ -581,8 +597,6 @@ class FrankaCabinetBench:
     """FrankaCabinet grasp transforms + obs(23) + 8-term reward + sticky done; target integration, resets."""
 
     def __init__(self, name, n, dev, seed, reset_frac=None):
-        if reset_frac is not None:
-            raise SystemExit("--reset-frac is not defined for this task (see the adapters that take it)")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -590,6 +604,8 @@ class FrankaCabinetBench:
         t = self.task
         st = workloads.franka_cabinet_state(n, t._env_pos, t.franka_local_grasp_pos[0], device=dev, seed=seed, num_dofs=t.NUM_DOFS,
                                             drawer_scale=0.45 if name == "FrankaCabinet" else 0.22)
+        if reset_frac is not None:  # the drawer joint's done threshold: 0.39 (franka_cabinet.py:601), 0.19 in the Tomo clones
+            _steady_cabinet_state(st, n, reset_frac, dev, seed, float(t.OPEN_DONE_THRESHOLD))
         workloads.load_franka_cabinet_state(t, st)
         for v in (t._frankas, t._cabinets, t._props):
             v.apply_resets = False
@@ -641,8 +657,6 @@ class NewhandCabinetBench:
     """the fork's five-finger cabinet tasks (10 keypoints, obs(2D+5), reward, sticky done [+ terminate])."""
 
     def __init__(self, name, n, dev, seed, reset_frac=None):
-        if reset_frac is not None:
-            raise SystemExit("--reset-frac is not defined for this task (see the adapters that take it)")
         from omniisaacgymenvs_amd.utils.task_util import make_task
         from omniisaacgymenvs_amd.sim import workloads
 
@@ -650,6 +664,10 @@ class NewhandCabinetBench:
         t = self.task
         st = workloads.newhand_cabinet_state(n, t._env_pos, t.robot_dof_lower_limits, t.robot_dof_upper_limits, t.num_actions, device=dev,
                                              seed=seed)
+        if reset_frac is not None:  # drawer below 0.19 and (Tendon's terminate_buf) every joint inside its limits
+            _steady_cabinet_state(st, n, reset_frac, dev, seed, 0.19)
+            lo_, hi_ = t.robot_dof_lower_limits.to(dev), t.robot_dof_upper_limits.to(dev)
+            st["dof_pos"] = torch.maximum(torch.minimum(st["dof_pos"], hi_), lo_).contiguous()
         workloads.load_newhand_cabinet_state(t, st)
         for v in (t._robots, t._cabinets, t._props):
             v.apply_resets = False

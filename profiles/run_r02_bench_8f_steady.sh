@@ -1,7 +1,7 @@
 #!/bin/bash
-# r02 steady-state bench lines (--reset-frac 0.001) of the section-8f tasks whose adapters define it, into gpurun_out/r02/
+# r02 steady-state bench lines (--reset-frac 0.001) of the section-8f tasks, into gpurun_out/r02/
 mkdir -p gpurun_out/r02
-for T in ${TASKS:-Anymal Quadcopter BallBalance Ingenuity Crazyflie}; do
+for T in ${TASKS:-Anymal AllegroHand Quadcopter BallBalance Ingenuity Crazyflie FrankaCabinet TomoDJCabinet TomoSPCCabinet TomoDJnewhandCabinet TomoDJnewhandTendonCabinet TomoSPCnewhandCabinet}; do
   timeout -k 10 200 python bench.py --task $T --steps 200 --warmup 20 --no-cpu-baseline --reset-frac 0.001 > gpurun_out/r02/bench_${T}_steady.json 2> gpurun_out/r02/bench_${T}_steady.err || { echo "$T failed"; tail -5 gpurun_out/r02/bench_${T}_steady.err; exit 1; }
   python3 - $T <<'PY'
 import json, sys
