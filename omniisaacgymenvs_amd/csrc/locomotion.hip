@@ -402,20 +402,24 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
   r.env_ids[k] = i;
 }
 
-template <int D>
+// SCANNED: the group offsets are in the workspace (scan_groups_kernel ran in front).  Otherwise the workgroup derives its
+// offset from the tile counts itself (group_rank_unscanned): one launch and one launch gap less per step, for 8 g bytes of
+// L2 reads per workgroup -- quadratic in the env count, so the host picks it up to UNSCANNED_MAX_GROUPS groups
+// (Humanoid at 512 K envs: step 130.5 -> 126.8 us; Ant at 1 M envs: pre kernel 36 -> 43 us, no gain, keeps the scan).
+constexpr int64_t UNSCANNED_MAX_GROUPS = 2048;
+
+template <int D, bool SCANNED>
 __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) {
-  __shared__ int lds4[GROUP_TILES];
+  __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP];
   const int64_t g = blockIdx.x;
   const int64_t env = g * GROUP + threadIdx.x;
   const int64_t G = num_groups(a.n);
-  const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
 
-  // Order: every load of the workgroup first (the reset flag, the group's offsets, the action quads, and - after the flagged
-  // envs are ranked - the reset rows), then every store: a load issued behind a store waits for that store's round trip.
+  // Order: every load of the workgroup first (the reset flag, the tile counts in front of the group, the action quads, and
+  // - after the flagged envs are ranked - the reset rows), then every store: a load issued behind a store waits for that
+  // store's round trip.
   const bool flagged = env < a.n && a.b.reset_buf[env] != 0;
-  const int32_t k0 = group_offsets[g];
-  const int cnt = group_offsets[g + 1] - k0;
 
   // forces = actions * joint_gears * power_scale (:125-126), lane-linear over the group's
   // contiguous 256*D floats; optional clamp (vec_env_rlgames.py:77) and clone (:125)
@@ -445,7 +449,16 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
   // into LDS so that the reset runs on DENSE lanes (thread j takes the group's j-th flagged env): with a few
   // flagged lanes per wave the divergent version spent 4 waves' worth of issue slots on ~10 % of the lanes, and
   // consecutive lanes now write consecutive compacted rows.
-  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
+  int k0, cnt;
+  int64_t k;
+  if (SCANNED) {
+    const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
+    k0 = group_offsets[g];
+    cnt = group_offsets[g + 1] - k0;
+    k = group_rank(flagged, group_offsets, g, lds8);
+  } else {
+    k = group_rank_unscanned(flagged, a.b.reset_workspace, g, lds8, k0, cnt);
+  }
   if (flagged) s_list[(int)(k - k0)] = (int)threadIdx.x;
   __syncthreads();
   const bool mine = (int)threadIdx.x < cnt;
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
     dst = a.r.dof_vel_out + (int64_t)k0 * D;
     for (int e = threadIdx.x; e < run; e += GROUP) dst[e] = s_rows[e];
   }
-  if (g == 0 && threadIdx.x == 0) *a.r.count = (int64_t)group_offsets[G];
+  if (g == G - 1 && threadIdx.x == 0) *a.r.count = (int64_t)k0 + cnt;
 }
 
 template <int D>
@@ -562,8 +575,12 @@ static int launch_pre(const LocoPre& a, hipStream_t s) {
   if (G == 0) return OIGE_OK;
   if (!(a.flags & OIGE_PRE_COUNTS_VALID))
     if (int rc = launch_count_flags(a.b.reset_buf, a.n, a.b.reset_workspace, s)) return rc;
-  if (int rc = launch_scan_groups(a.n, a.b.reset_workspace, s)) return rc;
-  hipLaunchKernelGGL((locomotion_pre_kernel<D>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  if (G <= UNSCANNED_MAX_GROUPS) {
+    hipLaunchKernelGGL((locomotion_pre_kernel<D, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else {
+    if (int rc = launch_scan_groups(a.n, a.b.reset_workspace, s)) return rc;
+    hipLaunchKernelGGL((locomotion_pre_kernel<D, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  }
   return check_launch("locomotion_pre_kernel");
 }
 
