@@ -205,8 +205,9 @@ __device__ __forceinline__ void anymal_flat_reset_head(const AnymalFlatPre& a, i
 // Order (r02): every load in front of the first store (the group's action and target quads, then -- after the ranks -- the
 // dense lanes' initial rows), per-DOF rows of the params in LDS (indexed in place by a run-time column they are vector
 // loads of the argument block): a load issued behind a store waits for that store's round trip.
+template <bool SCANNED>
 __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlatPre a) {
-  __shared__ int lds4[GROUP_TILES];
+  __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
   __shared__ float s_lo[FD], s_hi[FD], s_def[FD];
   const oige_anymal_flat_params& p = a.p;
@@ -214,15 +215,11 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
   const int64_t g = blockIdx.x;
   const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
-  const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
   const int64_t base = g * GROUP * FD;
   const int nf4 = (int)(envs_here * FD / 4);
   // ---- loads
   const bool flagged = env < a.n && a.b.reset_buf[env] != 0;  // :184
-  const int32_t k0 = group_offsets[g];
-  const int cnt = group_offsets[g + 1] - k0;
-  const int32_t total = group_offsets[G];
   float4 av[FD / 4], ct4[FD / 4];
 #pragma unroll
   for (int it = 0; it < FD / 4; ++it) {
@@ -236,7 +233,8 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
     s_hi[tid] = p.dof_upper[tid];
     s_def[tid] = p.default_dof_pos[tid];
   }
-  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
+  int k0, cnt;  // offset of the group in the id list, flagged envs in the group
+  const int64_t k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
   __syncthreads();
@@ -294,7 +292,7 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
       o[q] = tensor_clamp(ct[q] + (p.action_scale * aa[q]) * p.dt, s_lo[j0 + q], s_hi[j0 + q]);
     ST4S(a.b.current_targets + base + e, make_float4(o[0], o[1], o[2], o[3]));
   }
-  if (g == 0 && tid == 0) *a.r.count = (int64_t)total;
+  if (g == G - 1 && tid == 0) *a.r.count = (int64_t)k0 + cnt;
 }
 
 
@@ -414,8 +412,12 @@ int oige_anymal_flat_pre_physics(const oige_anymal_flat_params* params, const fl
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & OIGE_PRE_COUNTS_VALID))
     if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
-  if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-  hipLaunchKernelGGL(anymal_flat_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  if (G <= UNSCANNED_MAX_GROUPS) {
+    hipLaunchKernelGGL(anymal_flat_pre_kernel<false>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else {
+    if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
+    hipLaunchKernelGGL(anymal_flat_pre_kernel<true>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  }
   return check_launch("anymal_flat_pre_kernel");
 }
 

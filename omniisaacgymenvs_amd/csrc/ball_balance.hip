@@ -165,15 +165,15 @@ __device__ __forceinline__ void ball_draw(const BallPre& a, int64_t i, float (&u
   u[0] = u01(x.x); u[1] = u01(x.y); u[2] = u01(x.z); u[3] = u01(x.w); u[4] = u01(y.x);
 }
 
+template <bool SCANNED>
 __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a) {
-  __shared__ int lds4[GROUP_TILES];
+  __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP];
   const oige_ball_balance_params& p = a.p;
   const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
   const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
-  const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
   const bool flagged = live && a.b.reset_buf[env] != 0;  // :191
   // the env's own target row and actions, fetched in front of every store of the kernel (r02: a load issued behind a store
@@ -185,10 +185,8 @@ __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a
   for (int j = 0; j < BMAXD; ++j) tgv[j] = j < D ? a.b.dof_position_targets[le * D + j] : 0.0f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) ain[c] = a.actions_in[le * 3 + c];
-  const int32_t total = group_offsets[G];
-  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
-  const int32_t k0 = group_offsets[g];
-  const int cnt = group_offsets[g + 1] - k0;
+  int k0, cnt;  // offset of the group in the id list, flagged envs in the group
+  const int64_t k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   __syncthreads();
   wait_loads_done();
@@ -224,7 +222,7 @@ __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a
       }
     }
   }
-  if (g == 0 && tid == 0) *a.r.count = (int64_t)total;
+  if (g == G - 1 && tid == 0) *a.r.count = (int64_t)k0 + cnt;
 }
 
 __global__ __launch_bounds__(256) void ball_balance_reset_idx_kernel(const BallPre a, int64_t max_ids) {
@@ -318,8 +316,12 @@ int oige_ball_balance_pre_physics(const oige_ball_balance_params* params, const 
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & OIGE_PRE_COUNTS_VALID))
     if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
-  if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-  hipLaunchKernelGGL(ball_balance_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  if (G <= UNSCANNED_MAX_GROUPS) {
+    hipLaunchKernelGGL(ball_balance_pre_kernel<false>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else {
+    if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
+    hipLaunchKernelGGL(ball_balance_pre_kernel<true>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  }
   return check_launch("ball_balance_pre_kernel");
 }
 

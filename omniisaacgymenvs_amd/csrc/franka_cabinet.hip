@@ -224,9 +224,9 @@ __device__ __forceinline__ void franka_reset_rows(const FrankaPre& a, int64_t i,
   a.r.env_ids[k] = i;
 }
 
-template <int FD>
+template <int FD, bool SCANNED>
 __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaPre a) {
-  __shared__ int lds4[GROUP_TILES];
+  __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
   __shared__ float s_pos[GROUP * FD];
   __shared__ float s_lo[FD], s_hi[FD], s_rate[FD];
@@ -235,7 +235,6 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
   const int64_t g = blockIdx.x;
   const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
-  const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
   const bool flagged = live && a.b.reset_buf[env] != 0;  // :364
   // r02: the walk's action and target quads are fetched here, in front of every store of the kernel (a load issued behind a
@@ -260,10 +259,8 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
         if (e + c < total) { avq[it][c] = a.actions_in[base + e + c]; tvq[it][c] = a.b.franka_dof_targets[base + e + c]; }
     }
   }
-  const int32_t total_resets = group_offsets[G];
-  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
-  const int32_t k0 = group_offsets[g];
-  const int cnt = group_offsets[g + 1] - k0;
+  int k0, cnt;  // offset of the group in the id list, flagged envs in the group
+  const int64_t k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
 #pragma unroll
@@ -322,9 +319,9 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
         if (e + c < total) { a.b.actions[base + e + c] = av[c]; a.b.franka_dof_targets[base + e + c] = tv[c]; }
     }
   }
-  if (g == 0 && tid == 0) {
-    *a.r.count = (int64_t)total_resets;
-    *a.r.prop_count = (int64_t)total_resets * p.num_props;
+  if (g == G - 1 && tid == 0) {
+    *a.r.count = (int64_t)k0 + cnt;
+    *a.r.prop_count = ((int64_t)k0 + cnt) * p.num_props;
   }
 }
 
@@ -436,11 +433,16 @@ int oige_franka_cabinet_pre_physics(const oige_franka_cabinet_params* params, co
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & OIGE_PRE_COUNTS_VALID))
     if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
-  if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-  if (params->num_dofs == 9)
-    hipLaunchKernelGGL(franka_cabinet_pre_kernel<9>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
-  else
-    hipLaunchKernelGGL(franka_cabinet_pre_kernel<8>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  const bool scanned = G > UNSCANNED_MAX_GROUPS;
+  if (scanned)
+    if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
+  if (params->num_dofs == 9) {
+    if (scanned) hipLaunchKernelGGL((franka_cabinet_pre_kernel<9, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    else hipLaunchKernelGGL((franka_cabinet_pre_kernel<9, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else {
+    if (scanned) hipLaunchKernelGGL((franka_cabinet_pre_kernel<8, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    else hipLaunchKernelGGL((franka_cabinet_pre_kernel<8, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  }
   return check_launch("franka_cabinet_pre_kernel");
 }
 

@@ -404,10 +404,9 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
 
 // SCANNED: the group offsets are in the workspace (scan_groups_kernel ran in front).  Otherwise the workgroup derives its
 // offset from the tile counts itself (group_rank_unscanned): one launch and one launch gap less per step, for 8 g bytes of
-// L2 reads per workgroup -- quadratic in the env count, so the host picks it up to UNSCANNED_MAX_GROUPS groups
+// L2 reads per workgroup -- quadratic in the env count, so the host picks it up to LOCO_UNSCANNED_MAX_GROUPS groups
 // (Humanoid at 512 K envs: step 130.5 -> 126.8 us; Ant at 1 M envs: pre kernel 36 -> 43 us, no gain, keeps the scan).
-constexpr int64_t UNSCANNED_MAX_GROUPS = 2048;
-
+constexpr int64_t LOCO_UNSCANNED_MAX_GROUPS = 2048;
 template <int D, bool SCANNED>
 __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
@@ -451,14 +450,7 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
   // consecutive lanes now write consecutive compacted rows.
   int k0, cnt;
   int64_t k;
-  if (SCANNED) {
-    const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
-    k0 = group_offsets[g];
-    cnt = group_offsets[g + 1] - k0;
-    k = group_rank(flagged, group_offsets, g, lds8);
-  } else {
-    k = group_rank_unscanned(flagged, a.b.reset_workspace, g, lds8, k0, cnt);
-  }
+  k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = (int)threadIdx.x;
   __syncthreads();
   const bool mine = (int)threadIdx.x < cnt;
@@ -575,7 +567,7 @@ static int launch_pre(const LocoPre& a, hipStream_t s) {
   if (G == 0) return OIGE_OK;
   if (!(a.flags & OIGE_PRE_COUNTS_VALID))
     if (int rc = launch_count_flags(a.b.reset_buf, a.n, a.b.reset_workspace, s)) return rc;
-  if (G <= UNSCANNED_MAX_GROUPS) {
+  if (G <= LOCO_UNSCANNED_MAX_GROUPS) {
     hipLaunchKernelGGL((locomotion_pre_kernel<D, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
   } else {
     if (int rc = launch_scan_groups(a.n, a.b.reset_workspace, s)) return rc;

@@ -271,9 +271,9 @@ constexpr int NH_RMAX = 96;
 // 4-byte gather of `actions_in` per target element on top (26 per thread).  The clamped actions are staged in LDS for the
 // target walk (r01 tried that with the full 256-row reset staging beside it: 53 KB, three workgroups per CU; the reset
 // staging is now capped at NH_RMAX rows: 39 KB, four).
-template <int D, int A>
+template <int D, int A, bool SCANNED>
 __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre a) {
-  __shared__ int lds4[GROUP_TILES];
+  __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
   __shared__ __align__(16) float s_rows[NH_RMAX * D];  // new joint positions of the group's reset envs, compacted row order
   __shared__ __align__(16) float s_act[GROUP * A];      // the group's (clamped) actions
@@ -284,7 +284,6 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   const int64_t g = blockIdx.x;
   const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
-  const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
   const bool clampa = a.flags & OIGE_PRE_CLAMP_ACTIONS;
@@ -294,9 +293,6 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
 
   // ---- 0: loads
   const bool flagged = live && a.b.reset_buf[env] != 0;
-  const int32_t k0 = group_offsets[g];
-  const int cnt = group_offsets[g + 1] - k0;
-  const int32_t total_resets = group_offsets[G];
   float av[AIT][4], tv[TIT][4];
 #pragma unroll
   for (int it = 0; it < AIT; ++it) {
@@ -326,7 +322,8 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   }
 
   // ---- 1: ranks, lists, per-joint tables
-  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
+  int k0, cnt;  // offset of the group in the id list, flagged envs in the group
+  const int64_t k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
 #pragma unroll
@@ -442,9 +439,9 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
       dv[e] = 0.0f;
     }
   }
-  if (g == 0 && tid == 0) {
-    *a.r.count = (int64_t)total_resets;
-    *a.r.prop_count = (int64_t)total_resets * p.num_props;
+  if (g == G - 1 && tid == 0) {
+    *a.r.count = (int64_t)k0 + cnt;
+    *a.r.prop_count = ((int64_t)k0 + cnt) * p.num_props;
   }
   // ---- 6: prop rows of the reset envs, one prop per lane.  Last: these loads sit behind the kernel's stores, and nothing waits
   // for this part
@@ -571,13 +568,19 @@ int oige_newhand_cabinet_pre_physics(const oige_newhand_cabinet_params* params, 
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & OIGE_PRE_COUNTS_VALID))
     if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
-  if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-  if (params->num_dofs == 25)
-    hipLaunchKernelGGL((newhand_cabinet_pre_kernel<25, 25>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-  else if (params->num_actions == 22)
-    hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 22>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-  else
-    hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 26>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  const bool scanned = G > UNSCANNED_MAX_GROUPS;
+  if (scanned)
+    if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
+  if (params->num_dofs == 25) {
+    if (scanned) hipLaunchKernelGGL((newhand_cabinet_pre_kernel<25, 25, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    else hipLaunchKernelGGL((newhand_cabinet_pre_kernel<25, 25, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else if (params->num_actions == 22) {
+    if (scanned) hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 22, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    else hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 22, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else {
+    if (scanned) hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 26, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    else hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 26, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  }
   return check_launch("newhand_cabinet_pre_kernel");
 }
 

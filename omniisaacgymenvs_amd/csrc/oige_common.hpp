@@ -131,4 +131,23 @@ __device__ __forceinline__ int64_t group_rank_unscanned(bool flagged, const int3
   return flagged ? (int64_t)front + before + rank_below(mask) : -1;
 }
 
+// Up to this many groups (128 K envs) the pre kernels take the unscanned rank and their host code skips the scan launch:
+// the redundant reads grow with the square of the env count, and a kernel with few resident workgroups cannot hide them
+// (newhand_cabinet_pre_kernel at 2048 groups: 67 -> 74 us, against the 4 us scan launch it saved).  The locomotion pre kernel
+// has its own, higher limit (locomotion.hip).
+constexpr int64_t UNSCANNED_MAX_GROUPS = 512;
+
+// group_rank / group_rank_unscanned behind one call.  `ws` = the reset workspace (tile counts, then the group offsets when
+// SCANNED), `lds8` = 2 * GROUP_TILES ints.
+template <bool SCANNED>
+__device__ __forceinline__ int64_t group_rank_of(bool flagged, const int32_t* ws, int64_t G, int64_t g, int* lds8, int& k0, int& cnt) {
+  if (SCANNED) {
+    const int32_t* group_offsets = ws + G * GROUP_TILES;
+    k0 = group_offsets[g];
+    cnt = group_offsets[g + 1] - k0;
+    return group_rank(flagged, group_offsets, g, lds8);
+  }
+  return group_rank_unscanned(flagged, ws, g, lds8, k0, cnt);
+}
+
 }  // namespace oige

@@ -141,8 +141,9 @@ __device__ __forceinline__ float4 quad_dof_draw(const u4 x) {  // torch_rand_flo
 // Order (r02): every load in front of the first store (target and action quads of the lane-linear walk, the env's thrusts and
 // thrust actions, then -- behind the ranks -- the dense lanes' initial rows); the DOF limit rows in LDS (indexed in place by a
 // run-time column they are vector loads of the argument block).  A load issued behind a store waits for that store's round trip.
+template <bool SCANNED>
 __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) {
-  __shared__ int lds4[GROUP_TILES];
+  __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
   __shared__ float s_lo[QD], s_hi[QD];
   const oige_quadcopter_params& p = a.p;
@@ -150,15 +151,11 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
   const int64_t g = blockIdx.x;
   const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
-  const int32_t* group_offsets = a.b.reset_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
   const int nf4 = (int)(envs_here * QD / 4);
   // ---- loads
   const bool flagged = live && a.b.reset_buf[env] != 0;  // :147
-  const int32_t k0 = group_offsets[g];
-  const int cnt = group_offsets[g + 1] - k0;
-  const int32_t total = group_offsets[G];
   float4 tq[QD / 4], aq[QD / 4];
 #pragma unroll
   for (int it = 0; it < QD / 4; ++it) {
@@ -176,7 +173,8 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
     s_lo[tid] = p.dof_lower[tid];
     s_hi[tid] = p.dof_upper[tid];
   }
-  const int64_t k = group_rank(flagged, group_offsets, g, lds4);
+  int k0, cnt;  // offset of the group in the id list, flagged envs in the group
+  const int64_t k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
   __syncthreads();
@@ -252,7 +250,7 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
       fz[2] = th.x; fz[5] = th.y; fz[8] = th.z; fz[11] = th.w;
     }
   }
-  if (g == 0 && tid == 0) *a.r.count = (int64_t)total;
+  if (g == G - 1 && tid == 0) *a.r.count = (int64_t)k0 + cnt;
 }
 
 // reset_idx(env_ids) with caller-provided ids and (optionally) pre-drawn U[0,1): one thread per id
@@ -360,8 +358,12 @@ int oige_quadcopter_pre_physics(const oige_quadcopter_params* params, const floa
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & OIGE_PRE_COUNTS_VALID))
     if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
-  if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-  hipLaunchKernelGGL(quadcopter_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  if (G <= UNSCANNED_MAX_GROUPS) {
+    hipLaunchKernelGGL(quadcopter_pre_kernel<false>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else {
+    if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
+    hipLaunchKernelGGL(quadcopter_pre_kernel<true>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  }
   return check_launch("quadcopter_pre_kernel");
 }
 
