@@ -57,6 +57,7 @@ int oige_stream_copy(const void* src, void* dst, int64_t bytes, int32_t streams,
  */
 int64_t oige_num_tiles(int64_t n);
 int64_t oige_workspace_ints(int64_t n);
+int64_t oige_tile_counts_u8_bytes(int64_t n); /* size of oige_locomotion_buffers.tile_counts_u8 */
 int oige_count_flags_i64(const int64_t* flags, int64_t n, int32_t* workspace, oige_stream_t stream);
 int oige_compact_i64(const int64_t* flags, int64_t n, int32_t* workspace, int64_t* ids_out,
                      int64_t* count_out, oige_stream_t stream);
@@ -132,6 +133,13 @@ typedef struct oige_locomotion_buffers {
                                16-byte aligned.  The DONE stage leaves the per-tile counts of
                                non-zero reset flags here for the next pre_physics (may be NULL for
                                post_physics; required by pre_physics) */
+  uint8_t* tile_counts_u8;  /* optional (NULL = not used): oige_tile_counts_u8_bytes(N) bytes, 16-byte aligned.  The same
+                               per-tile counts as one byte each (a count is at most 64), written wherever the int32 ones
+                               are.  With it pre_physics derives each group's offset in the id list from the counts in
+                               front of it inside its own launch up to 4096 groups (1 M envs) instead of 2048: no scan
+                               launch between post_physics and pre_physics.  Pass the same buffer to post_physics and pre_physics (with
+                               OIGE_PRE_COUNTS_VALID the pre call trusts what the post call left in it).  No counterpart in the
+                               reference. */
 } oige_locomotion_buffers;
 
 /* stages of RLTask.post_physics_step (rl_task.py:289-295), any subset, executed in this order */

@@ -45,7 +45,7 @@ class LocomotionState(C.Structure):
 class LocomotionBuffers(C.Structure):
     _fields_ = [(n, _fp) for n in (
         "obs_buf", "rew_buf", "reset_buf", "progress_buf", "potentials", "prev_potentials", "up_vec", "heading_vec",
-        "actions", "reset_workspace")]
+        "actions", "reset_workspace", "tile_counts_u8")]
 
 
 class LocomotionResetIO(C.Structure):
@@ -345,6 +345,7 @@ SIGNATURES = {
     "oige_version": (C.c_int, []),
     "oige_num_tiles": (C.c_int64, [C.c_int64]),
     "oige_workspace_ints": (C.c_int64, [C.c_int64]),
+    "oige_tile_counts_u8_bytes": (C.c_int64, [C.c_int64]),
     "oige_count_flags_i64": (C.c_int, [_P, C.c_int64, _P, _P]),
     "oige_compact_i64": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P]),
     "oige_compact_static_max_envs": (C.c_int64, []),

@@ -222,6 +222,7 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
     if (live) a.b.reset_buf[env] = r;
     const unsigned long long m = __ballot(live && r != 0);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
+    if (a.b.tile_counts_u8 && lane == 0) a.b.tile_counts_u8[t] = (uint8_t)__popcll(m);
   }
   }  // env_wave
 
@@ -292,6 +293,7 @@ __global__ __launch_bounds__(256) void locomotion_done_kernel(const LocoPost a, 
   }
   const unsigned long long m = __ballot(live && r != 0);
   if (a.b.reset_workspace && lane_id() == 0) a.b.reset_workspace[env / TILE] = __popcll(m);
+  if (a.b.tile_counts_u8 && lane_id() == 0) a.b.tile_counts_u8[env / TILE] = (uint8_t)__popcll(m);
 }
 
 __global__ __launch_bounds__(256) void progress_increment_kernel(int64_t* __restrict__ progress, int64_t n) {
@@ -407,7 +409,10 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
 // L2 reads per workgroup -- quadratic in the env count, so the host picks it up to LOCO_UNSCANNED_MAX_GROUPS groups
 // (Humanoid at 512 K envs: step 130.5 -> 126.8 us; Ant at 1 M envs: pre kernel 36 -> 43 us, no gain, keeps the scan).
 constexpr int64_t LOCO_UNSCANNED_MAX_GROUPS = 2048;
-template <int D, bool SCANNED>
+// With the byte twin of the tile counts (oige_locomotion_buffers.tile_counts_u8) the prefix reads are a quarter: up to 4096 groups.
+constexpr int64_t LOCO_UNSCANNED_U8_MAX_GROUPS = 4096;
+constexpr int RANK_SCANNED = 0, RANK_INT32 = 1, RANK_U8 = 2;
+template <int D, int RANK>
 __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP];
@@ -450,7 +455,8 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
   // consecutive lanes now write consecutive compacted rows.
   int k0, cnt;
   int64_t k;
-  k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
+  if (RANK == RANK_U8) k = group_rank_unscanned_u8(flagged, a.b.tile_counts_u8, g, lds8, k0, cnt);
+  else k = group_rank_of<RANK == RANK_SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = (int)threadIdx.x;
   __syncthreads();
   const bool mine = (int)threadIdx.x < cnt;
@@ -566,12 +572,14 @@ static int launch_pre(const LocoPre& a, hipStream_t s) {
   const int64_t G = num_groups(a.n);
   if (G == 0) return OIGE_OK;
   if (!(a.flags & OIGE_PRE_COUNTS_VALID))
-    if (int rc = launch_count_flags(a.b.reset_buf, a.n, a.b.reset_workspace, s)) return rc;
-  if (G <= LOCO_UNSCANNED_MAX_GROUPS) {
-    hipLaunchKernelGGL((locomotion_pre_kernel<D, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    if (int rc = launch_count_flags(a.b.reset_buf, a.n, a.b.reset_workspace, s, a.b.tile_counts_u8)) return rc;
+  if (a.b.tile_counts_u8 && G <= LOCO_UNSCANNED_U8_MAX_GROUPS) {
+    hipLaunchKernelGGL((locomotion_pre_kernel<D, RANK_U8>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else if (G <= LOCO_UNSCANNED_MAX_GROUPS) {
+    hipLaunchKernelGGL((locomotion_pre_kernel<D, RANK_INT32>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
   } else {
     if (int rc = launch_scan_groups(a.n, a.b.reset_workspace, s)) return rc;
-    hipLaunchKernelGGL((locomotion_pre_kernel<D, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    hipLaunchKernelGGL((locomotion_pre_kernel<D, RANK_SCANNED>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
   }
   return check_launch("locomotion_pre_kernel");
 }
@@ -666,6 +674,7 @@ int oige_locomotion_pre_physics(const oige_locomotion_params* params, const floa
   const oige_locomotion_buffers& b = *buffers;
   OIGE_REQUIRE(b.reset_buf && b.progress_buf && b.potentials && b.prev_potentials && b.reset_workspace,
                "locomotion_pre_physics: null reset/progress/potentials/workspace");
+  OIGE_REQUIRE(!b.tile_counts_u8 || aligned16(b.tile_counts_u8), "locomotion_pre_physics: tile_counts_u8 must be 16-byte aligned");
   OIGE_REQUIRE(aligned16(actions_in) && aligned16(forces_out) && aligned16(actions_out) && aligned16(b.reset_workspace),
                "locomotion_pre_physics: actions/forces/workspace must be 16-byte aligned");
   LocoPre a;

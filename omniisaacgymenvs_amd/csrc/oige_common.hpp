@@ -50,7 +50,7 @@ __host__ __device__ inline int64_t padded_tiles(int64_t n) { return num_groups(n
 inline int64_t workspace_ints(int64_t n) { return padded_tiles(n) + num_groups(n) + 1; }
 
 // launches the count (optional) and scan kernels on `stream` (oige_core.hip)
-int launch_count_flags(const int64_t* flags, int64_t n, int32_t* ws, hipStream_t stream);
+int launch_count_flags(const int64_t* flags, int64_t n, int32_t* ws, hipStream_t stream, uint8_t* counts_u8 = nullptr);
 int launch_scan_groups(int64_t n, int32_t* ws, hipStream_t stream);
 int launch_scan_groups2(int64_t n, int32_t* ws_a, int32_t* ws_b, hipStream_t stream);  // two workspaces, one launch
 
@@ -117,6 +117,54 @@ __device__ __forceinline__ int64_t group_rank_unscanned(bool flagged, const int3
   if (lane_id() == 0 && w < GROUP_TILES) {
     lds8[w] = __popcll(mask);
     lds8[GROUP_TILES + w] = part;
+  }
+  __syncthreads();
+  int before = 0, all = 0, front = 0;
+#pragma unroll
+  for (int i = 0; i < GROUP_TILES; ++i) {
+    before += (i < w) ? lds8[i] : 0;
+    all += lds8[i];
+    front += lds8[GROUP_TILES + i];
+  }
+  k0 = front;
+  cnt = all;
+  return flagged ? (int64_t)front + before + rank_below(mask) : -1;
+}
+
+// The same from a BYTE per tile (a count is at most 64): word w of the table = the four tile counts of group w, so the
+// workgroup reads 4 g bytes instead of 16 g.  The table holds tile_counts_u8_bytes(n) bytes (whole 16-byte chunks).
+__host__ __device__ inline int64_t tile_counts_u8_bytes(int64_t n) { return 16 * ((num_groups(n) + 3) / 4); }
+
+__device__ __forceinline__ int64_t group_rank_unscanned_u8(bool flagged, const uint8_t* counts_u8, int64_t g, int* lds8, int& k0,
+                                                           int& cnt) {
+  const uint4* c4 = reinterpret_cast<const uint4*>(counts_u8);
+  const int64_t nq = (g + 3) / 4;  // 16-byte chunks that hold words [0, g)
+  unsigned part = 0;
+  constexpr int U = 4;
+  for (int64_t j0 = threadIdx.x; j0 < nq; j0 += (int64_t)U * GROUP) {
+    uint4 c[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // idle slots re-read a valid chunk (no load inside a conditional block)
+      const int64_t j = j0 + (int64_t)u * GROUP;
+      c[u] = c4[j < nq ? j : nq - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t w0 = 4 * (j0 + (int64_t)u * GROUP);  // first word of the chunk; words >= g belong to this group or later ones
+      part = __builtin_amdgcn_sad_u8(w0 < g ? c[u].x : 0u, 0u, part);  // v_sad_u8: the four bytes of a word summed in one operation
+      part = __builtin_amdgcn_sad_u8(w0 + 1 < g ? c[u].y : 0u, 0u, part);
+      part = __builtin_amdgcn_sad_u8(w0 + 2 < g ? c[u].z : 0u, 0u, part);
+      part = __builtin_amdgcn_sad_u8(w0 + 3 < g ? c[u].w : 0u, 0u, part);
+    }
+  }
+  int sum = (int)part;
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, WAVE);
+  const unsigned long long mask = __ballot(flagged);
+  const int w = threadIdx.x >> 6;
+  if (lane_id() == 0 && w < GROUP_TILES) {
+    lds8[w] = __popcll(mask);
+    lds8[GROUP_TILES + w] = sum;
   }
   __syncthreads();
   int before = 0, all = 0, front = 0;

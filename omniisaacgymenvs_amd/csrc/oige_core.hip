@@ -23,11 +23,15 @@ char* error_buffer() {
 }
 
 __global__ __launch_bounds__(GROUP) void count_flags_kernel(const int64_t* __restrict__ flags, int64_t n,
-                                                          int32_t* __restrict__ tile_counts) {
+                                                          int32_t* __restrict__ tile_counts, uint8_t* __restrict__ counts_u8) {
   const int64_t env = (int64_t)blockIdx.x * GROUP + threadIdx.x;
   const bool f = env < n && flags[env] != 0;
   const unsigned long long mask = __ballot(f);
-  if (lane_id() == 0) tile_counts[(int64_t)blockIdx.x * GROUP_TILES + (threadIdx.x >> 6)] = __popcll(mask);
+  if (lane_id() == 0) {
+    const int64_t t = (int64_t)blockIdx.x * GROUP_TILES + (threadIdx.x >> 6);
+    tile_counts[t] = __popcll(mask);
+    if (counts_u8) counts_u8[t] = (uint8_t)__popcll(mask);  // (the byte twin of the table, locomotion_pre_kernel)
+  }
 }
 
 // One workgroup of 1024 threads; thread i owns a contiguous run of groups (oige_scan.hpp).
@@ -72,10 +76,10 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restri
     st4_stream(reinterpret_cast<float*>(dst + s * per + i), ld4_stream(reinterpret_cast<const float*>(src + s * per + i)));
 }
 
-int launch_count_flags(const int64_t* flags, int64_t n, int32_t* ws, hipStream_t stream) {
+int launch_count_flags(const int64_t* flags, int64_t n, int32_t* ws, hipStream_t stream, uint8_t* counts_u8) {
   const int64_t G = num_groups(n);
   if (G == 0) return OIGE_OK;
-  hipLaunchKernelGGL(count_flags_kernel, dim3((unsigned)G), dim3(GROUP), 0, stream, flags, n, ws);
+  hipLaunchKernelGGL(count_flags_kernel, dim3((unsigned)G), dim3(GROUP), 0, stream, flags, n, ws, counts_u8);
   return check_launch("count_flags_kernel");
 }
 
@@ -129,6 +133,7 @@ const char* oige_last_error(void) { return error_buffer(); }
 int oige_version(void) { return OIGE_ABI_VERSION; }
 int64_t oige_num_tiles(int64_t n) { return n < 0 ? 0 : num_tiles(n); }
 int64_t oige_workspace_ints(int64_t n) { return n < 0 ? 0 : workspace_ints(n); }
+int64_t oige_tile_counts_u8_bytes(int64_t n) { return n < 0 ? 0 : tile_counts_u8_bytes(n); }
 
 int oige_stream_copy(const void* src, void* dst, int64_t bytes, int32_t streams, oige_stream_t stream) {
   OIGE_REQUIRE(src && dst && bytes >= 0 && aligned16(src) && aligned16(dst), "stream_copy: bad arguments");

@@ -29,6 +29,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature in _lib.py"
     assert lib.oige_version() == 1
     assert lib.oige_num_tiles(65) == 2 and lib.oige_workspace_ints(257) == 8 + 2 + 1
+    assert lib.oige_tile_counts_u8_bytes(257) == 16 and lib.oige_tile_counts_u8_bytes(256 * 5) == 32 and lib.oige_tile_counts_u8_bytes(0) == 0
 
 
 def test_struct_layouts_match_the_c_header(tmp_path):
@@ -82,7 +83,7 @@ def test_every_entry_point_rejects_null_arguments_without_touching_the_gpu():
     """All-NULL / zero arguments: every compute entry point must come back with a negative code and a message (never a
     crash, never a launch).  Validation runs before any HIP call, so this is safe without a device."""
     lib = _lib.load()
-    pure = {"oige_version", "oige_num_tiles", "oige_workspace_ints", "oige_last_error", "oige_compact_static_max_envs"}
+    pure = {"oige_version", "oige_num_tiles", "oige_workspace_ints", "oige_tile_counts_u8_bytes", "oige_last_error", "oige_compact_static_max_envs"}
     checked = 0
     for name, (res, args) in _lib.SIGNATURES.items():
         if name in pure:
