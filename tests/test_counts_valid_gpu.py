@@ -60,3 +60,46 @@ def test_shortcut_is_dropped_when_a_flag_buffer_moves(name):
     task.post_physics_step()
     task._post(_lib.STAGE_PROGRESS)  # a raw-pointer write to progress_buf
     assert not task._counts_valid(task.reset_buf, task.progress_buf)
+
+
+# ------------------------------------------------------------------ the three ways a locomotion pre kernel gets its group offsets
+def _ant(n, with_u8):
+    env, task = make_task("Ant", n, seed=5)
+    st = workloads.locomotion_state(n, task.dof_limits_lower, task.dof_limits_upper, task._num_sensors, device="cuda:0", seed=9,
+                                    z_range=(0.2, 0.9))
+    workloads.load_locomotion_state(task, st)
+    task._robots.apply_resets = False
+    if not with_u8:  # a caller that does not pass the byte twin of the tile counts: NULL in oige_locomotion_buffers
+        inner = task._buffers
+
+        def no_u8():
+            b = inner()
+            b.tile_counts_u8 = None
+            return b
+
+        task._buffers = no_u8
+    return task, st["actions"]
+
+
+@pytest.mark.parametrize("n", [257, 300_000, 600_000, 1 << 20])  # 2 / 1172 / 2344 / 4096 groups
+@pytest.mark.parametrize("recount", [False, True])
+def test_locomotion_offsets_from_bytes_ints_or_the_scan(n, recount):
+    """tile_counts_u8 (up to 4096 groups), the int32 counts (up to 2048) and the scan launch give the same ids and rows; with and
+    without OIGE_PRE_COUNTS_VALID (the count kernel writes the byte table too)."""
+    outs = []
+    for with_u8 in (True, False):
+        task, acts = _ant(n, with_u8)
+        task.post_physics_step()
+        if recount:
+            task._counts_key = None
+        task.pre_physics_step(acts)
+        torch.cuda.synchronize()
+        o = task._reset_out
+        k = int(o["count"].item())
+        assert k == int((o["env_ids"][:k] >= 0).sum()) and k > n // 20
+        outs.append([o["env_ids"][:k].clone(), o["dof_pos"][:k].clone(), o["dof_vel"][:k].clone(), o["root_pos"][:k].clone(),
+                     task.reset_buf.clone(), task.progress_buf.clone(), task._forces.clone(), task.potentials.clone()])
+    ids = outs[0][0]
+    assert torch.equal(ids, torch.sort(ids).values) and int(outs[0][4].sum()) == 0
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
