@@ -81,7 +81,7 @@ def _ant(n, with_u8):
     return task, st["actions"]
 
 
-@pytest.mark.parametrize("n", [257, 300_000, 600_000, 1 << 20])  # 2 / 1172 / 2344 / 4096 groups
+@pytest.mark.parametrize("n", [257, 300_000, 600_000, 1 << 20, (1 << 20) + 300])  # 2 / 1172 / 2344 / 4096 / 4098 groups (the last: scan)
 @pytest.mark.parametrize("recount", [False, True])
 def test_locomotion_offsets_from_bytes_ints_or_the_scan(n, recount):
     """tile_counts_u8 (up to 4096 groups), the int32 counts (up to 2048) and the scan launch give the same ids and rows; with and
@@ -92,11 +92,12 @@ def test_locomotion_offsets_from_bytes_ints_or_the_scan(n, recount):
         task.post_physics_step()
         if recount:
             task._counts_key = None
+        expected = task.reset_buf.nonzero().squeeze(-1)
         task.pre_physics_step(acts)
         torch.cuda.synchronize()
         o = task._reset_out
         k = int(o["count"].item())
-        assert k == int((o["env_ids"][:k] >= 0).sum()) and k > n // 20
+        assert k > n // 20 and torch.equal(o["env_ids"][:k], expected)  # == reset_buf.nonzero(), locomotion.py:121
         outs.append([o["env_ids"][:k].clone(), o["dof_pos"][:k].clone(), o["dof_vel"][:k].clone(), o["root_pos"][:k].clone(),
                      task.reset_buf.clone(), task.progress_buf.clone(), task._forces.clone(), task.potentials.clone()])
     ids = outs[0][0]
