@@ -521,6 +521,7 @@ typedef struct oige_anymal_flat_buffers {
   float* last_dof_vel;      /* (N,12) */
   float* current_targets;   /* (N,12); pre_physics / reset_idx only */
   int32_t* reset_workspace; /* oige_workspace_ints(N): tile counts of reset_buf */
+  uint8_t* tile_counts_u8;  /* optional: as oige_locomotion_buffers.tile_counts_u8 */
 } oige_anymal_flat_buffers;
 
 typedef struct oige_anymal_flat_reset_io {
@@ -655,6 +656,7 @@ typedef struct oige_quadcopter_buffers {
   float* thrusts;                /* (N,4) */
   float* forces;                 /* (N,4,3): only the z components are written, all three zeroed on reset (:163-170) */
   int32_t* reset_workspace;      /* as oige_locomotion_buffers.reset_workspace */
+  uint8_t* tile_counts_u8;  /* optional: as oige_locomotion_buffers.tile_counts_u8 */
 } oige_quadcopter_buffers;
 
 /* post_physics_step: progress += 1, get_observations (:124-141), calculate_metrics (:229-251), is_done (:253-261, NOT
@@ -725,6 +727,7 @@ typedef struct oige_ball_balance_buffers {
   int64_t* progress_buf;        /* (N,) */
   float* dof_position_targets;  /* (N,num_dof) */
   int32_t* reset_workspace;     /* as oige_locomotion_buffers.reset_workspace */
+  uint8_t* tile_counts_u8;  /* optional: as oige_locomotion_buffers.tile_counts_u8 */
 } oige_ball_balance_buffers;
 
 /* post_physics_step: progress += 1, get_observations (:159-185), calculate_metrics (:286-299), is_done (:301-308, sticky). */
@@ -1036,6 +1039,7 @@ typedef struct oige_franka_cabinet_buffers {
   float* drawer_grasp_rot;    /* (N,4) or NULL */
   float* drawer_grasp_pos;    /* (N,3) or NULL */
   int32_t* reset_workspace;   /* as oige_locomotion_buffers.reset_workspace */
+  uint8_t* tile_counts_u8;    /* optional: as oige_locomotion_buffers.tile_counts_u8 */
 } oige_franka_cabinet_buffers;
 
 /* post_physics_step: progress += 1, get_observations (:283-358, incl. compute_grasp_transforms :475-494),

@@ -172,7 +172,7 @@ class AnymalFlatState(C.Structure):
 
 class AnymalFlatBuffers(C.Structure):
     _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "commands", "actions", "last_actions",
-                                   "last_dof_vel", "current_targets", "reset_workspace")]
+                                   "last_dof_vel", "current_targets", "reset_workspace", "tile_counts_u8")]
 
 
 class AnymalFlatResetIO(C.Structure):
@@ -192,7 +192,7 @@ class QuadcopterState(C.Structure):
 
 class QuadcopterBuffers(C.Structure):
     _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "target_positions",
-                                   "dof_position_targets", "thrusts", "forces", "reset_workspace")]
+                                   "dof_position_targets", "thrusts", "forces", "reset_workspace", "tile_counts_u8")]
 
 
 class QuadcopterResetIO(C.Structure):
@@ -211,7 +211,7 @@ class BallBalanceState(C.Structure):
 
 
 class BallBalanceBuffers(C.Structure):
-    _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "dof_position_targets", "reset_workspace")]
+    _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "dof_position_targets", "reset_workspace", "tile_counts_u8")]
 
 
 class BallBalanceResetIO(C.Structure):
@@ -260,7 +260,7 @@ class FrankaCabinetState(C.Structure):
 
 class FrankaCabinetBuffers(C.Structure):
     _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "actions", "franka_dof_targets",
-                                   "franka_grasp_rot", "franka_grasp_pos", "drawer_grasp_rot", "drawer_grasp_pos", "reset_workspace")]
+                                   "franka_grasp_rot", "franka_grasp_pos", "drawer_grasp_rot", "drawer_grasp_pos", "reset_workspace", "tile_counts_u8")]
 
 
 class FrankaCabinetResetIO(C.Structure):
@@ -499,6 +499,11 @@ def workspace_ints(n: int) -> int:
 def new_workspace(n: int, device) -> torch.Tensor:
     """Zero-initialised int32 reset workspace (tile counts + group offsets)."""
     return torch.zeros(max(workspace_ints(n), 4), dtype=torch.int32, device=device)
+
+
+def new_tile_counts_u8(n: int, device) -> torch.Tensor:
+    """Zero-initialised byte twin of the tile counts (``*_buffers.tile_counts_u8``)."""
+    return torch.zeros(max(int(load().oige_tile_counts_u8_bytes(n)), 16), dtype=torch.uint8, device=device)
 
 
 def compact_static(flags: torch.Tensor, ids_out: torch.Tensor, count_out: torch.Tensor) -> None:

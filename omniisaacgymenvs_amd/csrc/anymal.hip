@@ -135,6 +135,7 @@ __device__ __forceinline__ void anymal_flat_tile(const AnymalFlatPost& a, float*
     if (live) a.b.reset_buf[env] = r ? 1 : 0;
     const unsigned long long m = __ballot(live && r);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
+    if (a.b.tile_counts_u8 && lane == 0) a.b.tile_counts_u8[t] = (uint8_t)__popcll(m);
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   if (do_obs) {
@@ -205,7 +206,7 @@ __device__ __forceinline__ void anymal_flat_reset_head(const AnymalFlatPre& a, i
 // Order (r02): every load in front of the first store (the group's action and target quads, then -- after the ranks -- the
 // dense lanes' initial rows), per-DOF rows of the params in LDS (indexed in place by a run-time column they are vector
 // loads of the argument block): a load issued behind a store waits for that store's round trip.
-template <bool SCANNED>
+template <int RANK>
 __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlatPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
     s_def[tid] = p.default_dof_pos[tid];
   }
   int k0, cnt;  // offset of the group in the id list, flagged envs in the group
-  const int64_t k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
+  const int64_t k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
   __syncthreads();
@@ -411,12 +412,15 @@ int oige_anymal_flat_pre_physics(const oige_anymal_flat_params* params, const fl
   if (G == 0) return OIGE_OK;
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & OIGE_PRE_COUNTS_VALID))
-    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
-  if (G <= UNSCANNED_MAX_GROUPS) {
-    hipLaunchKernelGGL(anymal_flat_pre_kernel<false>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s, a.b.tile_counts_u8)) return rc;
+  const int rank = pick_rank(G, a.b.tile_counts_u8);
+  if (rank == RANK_U8) {
+    hipLaunchKernelGGL(anymal_flat_pre_kernel<RANK_U8>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else if (rank == RANK_INT32) {
+    hipLaunchKernelGGL(anymal_flat_pre_kernel<RANK_INT32>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   } else {
     if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-    hipLaunchKernelGGL(anymal_flat_pre_kernel<true>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    hipLaunchKernelGGL(anymal_flat_pre_kernel<RANK_SCANNED>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   }
   return check_launch("anymal_flat_pre_kernel");
 }

@@ -85,6 +85,7 @@ __device__ __forceinline__ void ball_post_tile(const BallPost& a, float* __restr
     if (live) a.b.reset_buf[env] = r;
     const unsigned long long m = __ballot(live && r != 0);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
+    if (a.b.tile_counts_u8 && lane == 0) a.b.tile_counts_u8[t] = (uint8_t)__popcll(m);
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   __syncthreads();
@@ -165,7 +166,7 @@ __device__ __forceinline__ void ball_draw(const BallPre& a, int64_t i, float (&u
   u[0] = u01(x.x); u[1] = u01(x.y); u[2] = u01(x.z); u[3] = u01(x.w); u[4] = u01(y.x);
 }
 
-template <bool SCANNED>
+template <int RANK>
 __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP];
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a
 #pragma unroll
   for (int c = 0; c < 3; ++c) ain[c] = a.actions_in[le * 3 + c];
   int k0, cnt;  // offset of the group in the id list, flagged envs in the group
-  const int64_t k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
+  const int64_t k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   __syncthreads();
   wait_loads_done();
@@ -315,12 +316,15 @@ int oige_ball_balance_pre_physics(const oige_ball_balance_params* params, const 
   if (G == 0) return OIGE_OK;
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & OIGE_PRE_COUNTS_VALID))
-    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
-  if (G <= UNSCANNED_MAX_GROUPS) {
-    hipLaunchKernelGGL(ball_balance_pre_kernel<false>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s, a.b.tile_counts_u8)) return rc;
+  const int rank = pick_rank(G, a.b.tile_counts_u8);
+  if (rank == RANK_U8) {
+    hipLaunchKernelGGL(ball_balance_pre_kernel<RANK_U8>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else if (rank == RANK_INT32) {
+    hipLaunchKernelGGL(ball_balance_pre_kernel<RANK_INT32>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   } else {
     if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-    hipLaunchKernelGGL(ball_balance_pre_kernel<true>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    hipLaunchKernelGGL(ball_balance_pre_kernel<RANK_SCANNED>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   }
   return check_launch("ball_balance_pre_kernel");
 }

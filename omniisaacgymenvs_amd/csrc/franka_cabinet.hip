@@ -157,6 +157,7 @@ __device__ __forceinline__ void franka_post_tile(const FrankaPost& a, float* __r
     if (live) a.b.reset_buf[env] = out;
     const unsigned long long m = __ballot(live && r);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
+    if (a.b.tile_counts_u8 && lane == 0) a.b.tile_counts_u8[t] = (uint8_t)__popcll(m);
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   __syncthreads();
@@ -224,7 +225,7 @@ __device__ __forceinline__ void franka_reset_rows(const FrankaPre& a, int64_t i,
   a.r.env_ids[k] = i;
 }
 
-template <int FD, bool SCANNED>
+template <int FD, int RANK>
 __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
     }
   }
   int k0, cnt;  // offset of the group in the id list, flagged envs in the group
-  const int64_t k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
+  const int64_t k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
 #pragma unroll
@@ -432,16 +433,18 @@ int oige_franka_cabinet_pre_physics(const oige_franka_cabinet_params* params, co
   if (G == 0) return OIGE_OK;
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & OIGE_PRE_COUNTS_VALID))
-    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
-  const bool scanned = G > UNSCANNED_MAX_GROUPS;
-  if (scanned)
+    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s, a.b.tile_counts_u8)) return rc;
+  const int rank = pick_rank(G, a.b.tile_counts_u8);
+  if (rank == RANK_SCANNED)
     if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
   if (params->num_dofs == 9) {
-    if (scanned) hipLaunchKernelGGL((franka_cabinet_pre_kernel<9, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-    else hipLaunchKernelGGL((franka_cabinet_pre_kernel<9, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    if (rank == RANK_U8) hipLaunchKernelGGL((franka_cabinet_pre_kernel<9, RANK_U8>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    else if (rank == RANK_INT32) hipLaunchKernelGGL((franka_cabinet_pre_kernel<9, RANK_INT32>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    else hipLaunchKernelGGL((franka_cabinet_pre_kernel<9, RANK_SCANNED>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
   } else {
-    if (scanned) hipLaunchKernelGGL((franka_cabinet_pre_kernel<8, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-    else hipLaunchKernelGGL((franka_cabinet_pre_kernel<8, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    if (rank == RANK_U8) hipLaunchKernelGGL((franka_cabinet_pre_kernel<8, RANK_U8>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    else if (rank == RANK_INT32) hipLaunchKernelGGL((franka_cabinet_pre_kernel<8, RANK_INT32>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    else hipLaunchKernelGGL((franka_cabinet_pre_kernel<8, RANK_SCANNED>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
   }
   return check_launch("franka_cabinet_pre_kernel");
 }

@@ -409,9 +409,8 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
 // L2 reads per workgroup -- quadratic in the env count, so the host picks it up to LOCO_UNSCANNED_MAX_GROUPS groups
 // (Humanoid at 512 K envs: step 130.5 -> 126.8 us; Ant at 1 M envs: pre kernel 36 -> 43 us, no gain, keeps the scan).
 constexpr int64_t LOCO_UNSCANNED_MAX_GROUPS = 2048;
-// With the byte twin of the tile counts (oige_locomotion_buffers.tile_counts_u8) the prefix reads are a quarter: up to 4096 groups.
-constexpr int64_t LOCO_UNSCANNED_U8_MAX_GROUPS = 4096;
-constexpr int RANK_SCANNED = 0, RANK_INT32 = 1, RANK_U8 = 2;
+// With the byte twin of the tile counts (oige_locomotion_buffers.tile_counts_u8) the prefix reads are a quarter: up to
+// UNSCANNED_U8_MAX_GROUPS groups (oige_common.hpp).
 template <int D, int RANK>
 __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
@@ -455,8 +454,7 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
   // consecutive lanes now write consecutive compacted rows.
   int k0, cnt;
   int64_t k;
-  if (RANK == RANK_U8) k = group_rank_unscanned_u8(flagged, a.b.tile_counts_u8, g, lds8, k0, cnt);
-  else k = group_rank_of<RANK == RANK_SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
+  k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = (int)threadIdx.x;
   __syncthreads();
   const bool mine = (int)threadIdx.x < cnt;
@@ -573,9 +571,10 @@ static int launch_pre(const LocoPre& a, hipStream_t s) {
   if (G == 0) return OIGE_OK;
   if (!(a.flags & OIGE_PRE_COUNTS_VALID))
     if (int rc = launch_count_flags(a.b.reset_buf, a.n, a.b.reset_workspace, s, a.b.tile_counts_u8)) return rc;
-  if (a.b.tile_counts_u8 && G <= LOCO_UNSCANNED_U8_MAX_GROUPS) {
+  const int rank = pick_rank(G, a.b.tile_counts_u8, LOCO_UNSCANNED_MAX_GROUPS);
+  if (rank == RANK_U8) {
     hipLaunchKernelGGL((locomotion_pre_kernel<D, RANK_U8>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-  } else if (G <= LOCO_UNSCANNED_MAX_GROUPS) {
+  } else if (rank == RANK_INT32) {
     hipLaunchKernelGGL((locomotion_pre_kernel<D, RANK_INT32>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
   } else {
     if (int rc = launch_scan_groups(a.n, a.b.reset_workspace, s)) return rc;

@@ -198,4 +198,20 @@ __device__ __forceinline__ int64_t group_rank_of(bool flagged, const int32_t* ws
   return group_rank_unscanned(flagged, ws, g, lds8, k0, cnt);
 }
 
+// The three sources of a pre kernel's group offsets as one template parameter, and the host's choice between them.
+constexpr int RANK_SCANNED = 0, RANK_INT32 = 1, RANK_U8 = 2;
+constexpr int64_t UNSCANNED_U8_MAX_GROUPS = 4096;  // with the byte table the prefix reads are a quarter (1 M envs)
+
+template <int RANK>
+__device__ __forceinline__ int64_t group_rank_mode(bool flagged, const int32_t* ws, const uint8_t* counts_u8, int64_t G, int64_t g,
+                                                   int* lds8, int& k0, int& cnt) {
+  if (RANK == RANK_U8) return group_rank_unscanned_u8(flagged, counts_u8, g, lds8, k0, cnt);
+  return group_rank_of<RANK == RANK_SCANNED>(flagged, ws, G, g, lds8, k0, cnt);
+}
+
+inline int pick_rank(int64_t G, const uint8_t* counts_u8, int64_t int32_max_groups = UNSCANNED_MAX_GROUPS) {
+  if (counts_u8 && G <= UNSCANNED_U8_MAX_GROUPS) return RANK_U8;
+  return G <= int32_max_groups ? RANK_INT32 : RANK_SCANNED;
+}
+
 }  // namespace oige

@@ -87,6 +87,7 @@ __device__ __forceinline__ void quad_post_tile(const QuadPost& a, float* __restr
     if (live) a.b.reset_buf[env] = r ? 1 : 0;
     const unsigned long long m = __ballot(live && r);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
+    if (a.b.tile_counts_u8 && lane == 0) a.b.tile_counts_u8[t] = (uint8_t)__popcll(m);
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   __syncthreads();
@@ -141,7 +142,7 @@ __device__ __forceinline__ float4 quad_dof_draw(const u4 x) {  // torch_rand_flo
 // Order (r02): every load in front of the first store (target and action quads of the lane-linear walk, the env's thrusts and
 // thrust actions, then -- behind the ranks -- the dense lanes' initial rows); the DOF limit rows in LDS (indexed in place by a
 // run-time column they are vector loads of the argument block).  A load issued behind a store waits for that store's round trip.
-template <bool SCANNED>
+template <int RANK>
 __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
     s_hi[tid] = p.dof_upper[tid];
   }
   int k0, cnt;  // offset of the group in the id list, flagged envs in the group
-  const int64_t k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
+  const int64_t k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
   __syncthreads();
@@ -357,12 +358,15 @@ int oige_quadcopter_pre_physics(const oige_quadcopter_params* params, const floa
   if (G == 0) return OIGE_OK;
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & OIGE_PRE_COUNTS_VALID))
-    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
-  if (G <= UNSCANNED_MAX_GROUPS) {
-    hipLaunchKernelGGL(quadcopter_pre_kernel<false>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s, a.b.tile_counts_u8)) return rc;
+  const int rank = pick_rank(G, a.b.tile_counts_u8);
+  if (rank == RANK_U8) {
+    hipLaunchKernelGGL(quadcopter_pre_kernel<RANK_U8>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else if (rank == RANK_INT32) {
+    hipLaunchKernelGGL(quadcopter_pre_kernel<RANK_INT32>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   } else {
     if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-    hipLaunchKernelGGL(quadcopter_pre_kernel<true>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    hipLaunchKernelGGL(quadcopter_pre_kernel<RANK_SCANNED>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
   }
   return check_launch("quadcopter_pre_kernel");
 }

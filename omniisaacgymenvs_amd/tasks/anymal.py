@@ -92,6 +92,7 @@ class AnymalTask(RLTask):
 
         # device-side scratch of the HIP path
         self._reset_workspace = _lib.new_workspace(n, dev)
+        self._tile_counts_u8 = _lib.new_tile_counts_u8(n, dev)
         i64 = dict(dtype=torch.int64, device=dev)
         self._reset_out = {
             "env_ids": torch.zeros(n, **i64), "count": torch.zeros(1, **i64),
@@ -139,6 +140,7 @@ class AnymalTask(RLTask):
         b.commands, b.actions = self.commands.data_ptr(), self.actions.data_ptr()
         b.last_actions, b.last_dof_vel = self.last_actions.data_ptr(), self.last_dof_vel.data_ptr()
         b.current_targets, b.reset_workspace = self.current_targets.data_ptr(), self._reset_workspace.data_ptr()
+        b.tile_counts_u8 = self._tile_counts_u8.data_ptr()
         return b
 
     def _state(self) -> _lib.AnymalFlatState:

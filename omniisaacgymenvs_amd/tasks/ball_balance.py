@@ -84,6 +84,7 @@ class BallBalanceTask(RLTask):
         # device-side scratch of the HIP path
         d = self._balance_bots.num_dof
         self._reset_workspace = _lib.new_workspace(n, dev)
+        self._tile_counts_u8 = _lib.new_tile_counts_u8(n, dev)
         i64 = dict(dtype=torch.int64, device=dev)
         self._reset_out = {
             "env_ids": torch.zeros(n, **i64), "count": torch.zeros(1, **i64),
@@ -121,6 +122,7 @@ class BallBalanceTask(RLTask):
         b.obs_buf, b.rew_buf = self.obs_buf.data_ptr(), self.rew_buf.data_ptr()
         b.reset_buf, b.progress_buf = self.reset_buf.data_ptr(), self.progress_buf.data_ptr()
         b.dof_position_targets, b.reset_workspace = self.dof_position_targets.data_ptr(), self._reset_workspace.data_ptr()
+        b.tile_counts_u8 = self._tile_counts_u8.data_ptr()
         return b
 
     def _state(self) -> _lib.BallBalanceState:

@@ -176,6 +176,7 @@ class FrankaCabinetTask(RLTask):
             self.default_prop_pos, self.default_prop_rot = self._props.get_world_poses()
             self.prop_indices = torch.arange(n * P, device=dev).view(n, P)
         self._reset_workspace = _lib.new_workspace(n, dev)
+        self._tile_counts_u8 = _lib.new_tile_counts_u8(n, dev)
         i64 = dict(dtype=torch.int64, device=dev)
         self._reset_out = {
             "env_ids": torch.zeros(n, **i64), "count": torch.zeros(1, **i64),
@@ -232,6 +233,7 @@ class FrankaCabinetTask(RLTask):
         b.franka_grasp_rot, b.franka_grasp_pos = self.franka_grasp_rot.data_ptr(), self.franka_grasp_pos.data_ptr()
         b.drawer_grasp_rot, b.drawer_grasp_pos = self.drawer_grasp_rot.data_ptr(), self.drawer_grasp_pos.data_ptr()
         b.reset_workspace = self._reset_workspace.data_ptr()
+        b.tile_counts_u8 = self._tile_counts_u8.data_ptr()
         return b
 
     def _state(self) -> _lib.FrankaCabinetState:

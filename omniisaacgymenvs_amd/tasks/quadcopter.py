@@ -86,6 +86,7 @@ class QuadcopterTask(RLTask):
 
         # device-side scratch of the HIP path
         self._reset_workspace = _lib.new_workspace(n, dev)
+        self._tile_counts_u8 = _lib.new_tile_counts_u8(n, dev)
         i64 = dict(dtype=torch.int64, device=dev)
         self._reset_out = {
             "env_ids": torch.zeros(n, **i64), "count": torch.zeros(1, **i64),
@@ -123,6 +124,7 @@ class QuadcopterTask(RLTask):
         b.reset_buf, b.progress_buf = self.reset_buf.data_ptr(), self.progress_buf.data_ptr()
         b.target_positions, b.dof_position_targets = self.target_positions.data_ptr(), self.dof_position_targets.data_ptr()
         b.thrusts, b.forces, b.reset_workspace = self.thrusts.data_ptr(), self.forces.data_ptr(), self._reset_workspace.data_ptr()
+        b.tile_counts_u8 = self._tile_counts_u8.data_ptr()
         return b
 
     def _state(self) -> _lib.QuadcopterState:

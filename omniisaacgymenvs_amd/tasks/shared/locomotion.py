@@ -312,7 +312,7 @@ class LocomotionTask(RLTask):
         f = dict(dtype=torch.float32, device=dev)
         self._forces = torch.zeros((n, d), **f)
         self._reset_workspace = _lib.new_workspace(n, dev)
-        self._tile_counts_u8 = torch.zeros(max(int(_lib.load().oige_tile_counts_u8_bytes(n)), 16), dtype=torch.uint8, device=dev)
+        self._tile_counts_u8 = _lib.new_tile_counts_u8(n, dev)
         self._reset_out = {
             "env_ids": torch.zeros(n, dtype=torch.int64, device=dev),
             "count": torch.zeros(1, dtype=torch.int64, device=dev),
