@@ -799,6 +799,8 @@ typedef struct oige_ingenuity_buffers {
   float* dof_vel;            /* (N,4) the task's own copy; zeroed on reset, columns 1 / 3 = +-50 every step (:178-179) */
   int32_t* reset_workspace;  /* oige_workspace_ints(N): reset ids */
   int32_t* target_workspace; /* oige_workspace_ints(N): set_targets ids */
+  uint8_t* reset_counts_u8;  /* optional, both or neither: the two tables' tile counts as bytes, */
+  uint8_t* target_counts_u8; /*   as oige_locomotion_buffers.tile_counts_u8                      */
 } oige_ingenuity_buffers;
 
 /* post_physics_step: progress += 1, get_observations (:128-147), calculate_metrics (:244-268), is_done (:270-281). */

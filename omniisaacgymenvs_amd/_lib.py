@@ -232,7 +232,7 @@ class IngenuityState(C.Structure):
 
 class IngenuityBuffers(C.Structure):
     _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "target_positions", "thrusts", "dof_pos",
-                                   "dof_vel", "reset_workspace", "target_workspace")]
+                                   "dof_vel", "reset_workspace", "target_workspace", "reset_counts_u8", "target_counts_u8")]
 
 
 class IngenuityResetIO(C.Structure):

@@ -77,10 +77,12 @@ __device__ __forceinline__ void ing_post_tile(const IngPost& a, float* __restric
     if (live) a.b.reset_buf[env] = r ? 1 : 0;
     const unsigned long long m = __ballot(live && r);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
+    if (a.b.reset_counts_u8 && lane == 0) a.b.reset_counts_u8[t] = (uint8_t)__popcll(m);
     // and of the second list the next pre_physics_step compacts (reset or progress % 500 == 0, :154-160), so that it can
     // skip its counting launch (OIGE_PRE_COUNTS_VALID)
     const unsigned long long mt = __ballot(live && (r || progress % 500 == 0));
     if (a.b.target_workspace && lane == 0) a.b.target_workspace[t] = __popcll(mt);
+    if (a.b.target_counts_u8 && lane == 0) a.b.target_counts_u8[t] = (uint8_t)__popcll(mt);
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   __syncthreads();
@@ -118,6 +120,8 @@ __global__ __launch_bounds__(GROUP) void ingenuity_count_kernel(const IngPre a) 
     const int64_t t = env / TILE;
     a.b.reset_workspace[t] = __popcll(mr);
     a.b.target_workspace[t] = __popcll(mt);
+    if (a.b.reset_counts_u8) a.b.reset_counts_u8[t] = (uint8_t)__popcll(mr);
+    if (a.b.target_counts_u8) a.b.target_counts_u8[t] = (uint8_t)__popcll(mt);
   }
 }
 
@@ -158,16 +162,16 @@ __device__ __forceinline__ void ing_set_target(const IngPre& a, int64_t i, int64
   a.r.target_ids[k] = i;
 }
 
+// RANK: where the two lists' group offsets come from (oige_common.hpp: the scan launch, the int32 tile counts, their byte twins)
+template <int RANK>
 __global__ __launch_bounds__(GROUP) void ingenuity_pre_kernel(const IngPre a) {
-  __shared__ int lds_a[GROUP_TILES], lds_b[GROUP_TILES];
+  __shared__ int lds_a[2 * GROUP_TILES], lds_b[2 * GROUP_TILES];
   __shared__ int s_list_r[GROUP], s_list_t[GROUP];
   const oige_ingenuity_params& p = a.p;
   const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
   const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
-  const int32_t* off_r = a.b.reset_workspace + G * GROUP_TILES;
-  const int32_t* off_t = a.b.target_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
   const bool fr = live && a.b.reset_buf[env] != 0;
   const bool ft = live && (fr || a.b.progress_buf[env] % 500 == 0);
@@ -177,11 +181,9 @@ __global__ __launch_bounds__(GROUP) void ingenuity_pre_kernel(const IngPre a) {
   const float2* ar = reinterpret_cast<const float2*>(a.actions_in + le * 6);
   const float2 a0 = ar[0], a1 = ar[1], a2 = ar[2];
   const float4 dv_in = *reinterpret_cast<const float4*>(a.b.dof_vel + le * 4);
-  const int32_t total_r = off_r[G], total_t = off_t[G];
-  const int64_t kr = group_rank(fr, off_r, g, lds_a);
-  const int64_t kt = group_rank(ft, off_t, g, lds_b);
-  const int32_t k0r = off_r[g], k0t = off_t[g];
-  const int cntr = off_r[g + 1] - k0r, cntt = off_t[g + 1] - k0t;
+  int k0r, cntr, k0t, cntt;
+  const int64_t kr = group_rank_mode<RANK>(fr, a.b.reset_workspace, a.b.reset_counts_u8, G, g, lds_a, k0r, cntr);
+  const int64_t kt = group_rank_mode<RANK>(ft, a.b.target_workspace, a.b.target_counts_u8, G, g, lds_b, k0t, cntt);
   if (fr) s_list_r[(int)(kr - k0r)] = tid;
   if (ft) s_list_t[(int)(kt - k0t)] = tid;
   __syncthreads();
@@ -226,9 +228,9 @@ __global__ __launch_bounds__(GROUP) void ingenuity_pre_kernel(const IngPre a) {
     dv.w = -50.0f;
     *reinterpret_cast<float4*>(a.b.dof_vel + env * 4) = dv;
   }
-  if (g == 0 && tid == 0) {
-    *a.r.count = (int64_t)total_r;
-    *a.r.target_count = (int64_t)total_t;
+  if (g == G - 1 && tid == 0) {
+    *a.r.count = (int64_t)k0r + cntr;
+    *a.r.target_count = (int64_t)k0t + cntt;
   }
 }
 
@@ -341,6 +343,8 @@ int oige_ingenuity_pre_physics(const oige_ingenuity_params* params, const float*
   OIGE_REQUIRE(actions_in && (reinterpret_cast<uintptr_t>(actions_in) & 7u) == 0, "ingenuity_pre_physics: null/unaligned actions");
   OIGE_REQUIRE(a.b.thrusts && a.b.dof_vel && aligned16(a.b.dof_vel) && (reinterpret_cast<uintptr_t>(a.b.thrusts) & 7u) == 0,
                "ingenuity_pre_physics: null/unaligned thrusts / dof_vel");
+  OIGE_REQUIRE((!a.b.reset_counts_u8 || aligned16(a.b.reset_counts_u8)) && (!a.b.target_counts_u8 || aligned16(a.b.target_counts_u8)),
+               "ingenuity_pre_physics: the byte count tables must be 16-byte aligned");
   OIGE_REQUIRE(a.b.reset_workspace && a.b.target_workspace && aligned16(a.b.reset_workspace) && aligned16(a.b.target_workspace),
                "ingenuity_pre_physics: null/unaligned workspaces");
   OIGE_REQUIRE(!a.r.u_reset && !a.r.u_target, "ingenuity_pre_physics: pre-drawn noise goes through oige_ingenuity_reset_idx / _set_targets");
@@ -353,8 +357,15 @@ int oige_ingenuity_pre_physics(const oige_ingenuity_params* params, const float*
     hipLaunchKernelGGL(ingenuity_count_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
     if (int rc = check_launch("ingenuity_count_kernel")) return rc;
   }
-  if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.target_workspace, s)) return rc;
-  hipLaunchKernelGGL(ingenuity_pre_kernel, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  const int rank = pick_rank(G, a.b.reset_counts_u8 && a.b.target_counts_u8 ? a.b.reset_counts_u8 : nullptr);
+  if (rank == RANK_U8) {
+    hipLaunchKernelGGL(ingenuity_pre_kernel<RANK_U8>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else if (rank == RANK_INT32) {
+    hipLaunchKernelGGL(ingenuity_pre_kernel<RANK_INT32>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  } else {
+    if (int rc = launch_scan_groups2(num_envs, a.b.reset_workspace, a.b.target_workspace, s)) return rc;
+    hipLaunchKernelGGL(ingenuity_pre_kernel<RANK_SCANNED>, dim3((unsigned)G), dim3(GROUP), 0, s, a);
+  }
   return check_launch("ingenuity_pre_kernel");
 }
 

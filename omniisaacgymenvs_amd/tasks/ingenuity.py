@@ -82,6 +82,7 @@ class IngenuityTask(RLTask):
         # device-side scratch of the HIP path
         self._reset_workspace = _lib.new_workspace(n, dev)
         self._target_workspace = _lib.new_workspace(n, dev)
+        self._reset_counts_u8, self._target_counts_u8 = _lib.new_tile_counts_u8(n, dev), _lib.new_tile_counts_u8(n, dev)
         i64 = dict(dtype=torch.int64, device=dev)
         self._reset_out = {
             "env_ids": torch.zeros(n, **i64), "count": torch.zeros(1, **i64),
@@ -115,6 +116,7 @@ class IngenuityTask(RLTask):
         b.target_positions, b.thrusts = self.target_positions.data_ptr(), self.thrusts.data_ptr()
         b.dof_pos, b.dof_vel = self.dof_pos.data_ptr(), self.dof_vel.data_ptr()
         b.reset_workspace, b.target_workspace = self._reset_workspace.data_ptr(), self._target_workspace.data_ptr()
+        b.reset_counts_u8, b.target_counts_u8 = self._reset_counts_u8.data_ptr(), self._target_counts_u8.data_ptr()
         return b
 
     def _state(self) -> _lib.IngenuityState:
