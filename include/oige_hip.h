@@ -1136,6 +1136,7 @@ typedef struct oige_newhand_cabinet_buffers {
   int32_t* reset_workspace;  /* as oige_locomotion_buffers.reset_workspace */
   float* actuated_targets_out; /* (N,A) or NULL: pre_physics also writes dof_targets[:, actuated_dof_indices], the block the Tendon
                                 * task hands to set_joint_position_targets(joint_indices=...) (tomodj_newhandTendon_cabinet.py) */
+  uint8_t* tile_counts_u8;       /* optional: as oige_locomotion_buffers.tile_counts_u8 */
 } oige_newhand_cabinet_buffers;
 
 /* post_physics_step: progress += 1, get_observations, calculate_metrics (compute_*_reward), is_done.  `stages` as for locomotion. */

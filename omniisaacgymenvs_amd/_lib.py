@@ -288,7 +288,7 @@ class NewhandCabinetState(C.Structure):
 
 class NewhandCabinetBuffers(C.Structure):
     _fields_ = [(n, _fp) for n in ("obs_buf", "rew_buf", "reset_buf", "progress_buf", "actions", "dof_targets", "keypoints_finger",
-                                   "keypoints_drawer", "terminate_buf", "reset_workspace", "actuated_targets_out")]
+                                   "keypoints_drawer", "terminate_buf", "reset_workspace", "actuated_targets_out", "tile_counts_u8")]
 
 
 OBSERVER_MAX_KEYS = 64

@@ -180,6 +180,7 @@ __device__ __forceinline__ void nh_post_tile(const NhPost& a, float* __restrict_
     }
     const unsigned long long m = __ballot(live && r);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
+    if (a.b.tile_counts_u8 && lane == 0) a.b.tile_counts_u8[t] = (uint8_t)__popcll(m);
   }
   if (do_progress && live) a.b.progress_buf[env] = progress;
   __syncthreads();
@@ -271,7 +272,7 @@ constexpr int NH_RMAX = 96;
 // 4-byte gather of `actions_in` per target element on top (26 per thread).  The clamped actions are staged in LDS for the
 // target walk (r01 tried that with the full 256-row reset staging beside it: 53 KB, three workgroups per CU; the reset
 // staging is now capped at NH_RMAX rows: 39 KB, four).
-template <int D, int A, bool SCANNED>
+template <int D, int A, int RANK>
 __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP], s_rank[GROUP];
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
 
   // ---- 1: ranks, lists, per-joint tables
   int k0, cnt;  // offset of the group in the id list, flagged envs in the group
-  const int64_t k = group_rank_of<SCANNED>(flagged, a.b.reset_workspace, G, g, lds8, k0, cnt);
+  const int64_t k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
 #pragma unroll
@@ -567,20 +568,20 @@ int oige_newhand_cabinet_pre_physics(const oige_newhand_cabinet_params* params, 
   if (G == 0) return OIGE_OK;
   hipStream_t s = (hipStream_t)stream;
   if (!(flags & OIGE_PRE_COUNTS_VALID))
-    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s)) return rc;
-  const bool scanned = G > UNSCANNED_MAX_GROUPS;
-  if (scanned)
+    if (int rc = launch_count_flags(a.b.reset_buf, num_envs, a.b.reset_workspace, s, a.b.tile_counts_u8)) return rc;
+  const int rank = pick_rank(G, a.b.tile_counts_u8);
+  if (rank == RANK_SCANNED)
     if (int rc = launch_scan_groups(num_envs, a.b.reset_workspace, s)) return rc;
-  if (params->num_dofs == 25) {
-    if (scanned) hipLaunchKernelGGL((newhand_cabinet_pre_kernel<25, 25, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-    else hipLaunchKernelGGL((newhand_cabinet_pre_kernel<25, 25, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-  } else if (params->num_actions == 22) {
-    if (scanned) hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 22, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-    else hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 22, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-  } else {
-    if (scanned) hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 26, true>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-    else hipLaunchKernelGGL((newhand_cabinet_pre_kernel<26, 26, false>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
-  }
+#define OIGE_NH_PRE(D_, A_)                                                                                                  \
+  do {                                                                                                                       \
+    if (rank == RANK_U8) hipLaunchKernelGGL((newhand_cabinet_pre_kernel<D_, A_, RANK_U8>), dim3((unsigned)G), dim3(GROUP), 0, s, a); \
+    else if (rank == RANK_INT32) hipLaunchKernelGGL((newhand_cabinet_pre_kernel<D_, A_, RANK_INT32>), dim3((unsigned)G), dim3(GROUP), 0, s, a); \
+    else hipLaunchKernelGGL((newhand_cabinet_pre_kernel<D_, A_, RANK_SCANNED>), dim3((unsigned)G), dim3(GROUP), 0, s, a);     \
+  } while (0)
+  if (params->num_dofs == 25) OIGE_NH_PRE(25, 25);
+  else if (params->num_actions == 22) OIGE_NH_PRE(26, 22);
+  else OIGE_NH_PRE(26, 26);
+#undef OIGE_NH_PRE
   return check_launch("newhand_cabinet_pre_kernel");
 }
 

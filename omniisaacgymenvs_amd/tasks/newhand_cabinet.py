@@ -161,6 +161,7 @@ class _NewhandCabinetTask(RLTask):
             self.prop_indices = torch.arange(n * P, device=dev).view(n, P)
         self.terminate_buf = torch.zeros_like(self.reset_buf)
         self._reset_workspace = _lib.new_workspace(n, dev)
+        self._tile_counts_u8 = _lib.new_tile_counts_u8(n, dev)
         i64 = dict(dtype=torch.int64, device=dev)
         self._reset_out = {
             "env_ids": torch.zeros(n, **i64), "count": torch.zeros(1, **i64),
@@ -224,6 +225,7 @@ class _NewhandCabinetTask(RLTask):
         b.actions, b.dof_targets = self.actions.data_ptr(), self.robot_dof_targets.data_ptr()
         b.keypoints_finger, b.keypoints_drawer = self.keypoints_finger.data_ptr(), self.keypoints_drawer.data_ptr()
         b.terminate_buf, b.reset_workspace = self.terminate_buf.data_ptr(), self._reset_workspace.data_ptr()
+        b.tile_counts_u8 = self._tile_counts_u8.data_ptr()
         if self.ACTUATED is not None:  # Tendon: robot_dof_targets[:, actuated_dof_indices] comes out of the pre kernel
             if getattr(self, "_actuated_targets", None) is None:
                 self._actuated_targets = torch.zeros(n, self.num_actions, dtype=torch.float32, device=self._device)
