@@ -421,6 +421,9 @@ typedef struct oige_anymal_buffers {
   int32_t* reset_workspace;  /* oige_workspace_ints(N) */
   float* reduce_workspace;   /* (16 + 512) * oige_num_tiles(N) + 4 floats, 16-byte aligned: per-tile partial sums, then
                                 the 8-float pose record per env that the head kernel hands to the scan kernel */
+  uint8_t* tile_counts_u8;   /* optional: oige_tile_counts_u8_bytes(N) bytes, 16-byte aligned (as oige_locomotion_buffers.
+                                tile_counts_u8).  With it, up to 4096 groups, the step runs without its scan + norm launch: the
+                                head kernel's waves derive their offset in the id list and the command norm (:376) themselves */
 } oige_anymal_buffers;
 
 /* reset rows for the view setters (:334-339), compacted in ascending env order */

@@ -145,7 +145,7 @@ class AnymalBuffers(C.Structure):
     _fields_ = [(n, _fp) for n in (
         "obs_buf", "rew_buf", "reset_buf", "has_fallen", "timeout_buf", "progress_buf", "commands", "actions",
         "last_actions", "last_dof_vel", "torques", "feet_air_time", "episode_sums", "terrain_levels", "terrain_types",
-        "env_origins", "extras", "reset_workspace", "reduce_workspace")]
+        "env_origins", "extras", "reset_workspace", "reduce_workspace", "tile_counts_u8")]
 
 
 class AnymalResetIO(C.Structure):

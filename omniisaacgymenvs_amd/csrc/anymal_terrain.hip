@@ -37,6 +37,10 @@ struct AnymalPost {
   oige_anymal_reset_io r;
   int64_t n;
   int mode;  // 0: post_physics_step, 1: standalone reset_idx(env_ids) driven by r.reset_mask
+  // 1: no scan / norm launch between the flags and the head kernel.  The flags kernel leaves the tile counts as bytes too
+  // (b.tile_counts_u8) and one partial sum of the command norm per GROUP in the workspace's group-offset slots; a head wave
+  // that holds a reset env sums both itself, and the last tile's wave leaves the total where the scan would have.
+  int unscanned;
 };
 
 // wrap_to_pi AS TORCHSCRIPT RUNS IT (:615-619): `angles %= 2*pi` of a scripted function is aten::fmod_
@@ -136,6 +140,16 @@ __global__ __launch_bounds__(GROUP) void anymal_flags_kernel(const AnymalPost a)
     const int64_t t = env / TILE;
     a.b.reset_workspace[t] = __popcll(m);
     if (t < num_tiles(a.n)) a.b.reduce_workspace[t * RW + 0] = s;
+  }
+  if (a.unscanned) {  // (uniform)
+    __shared__ float s_cmd2[GROUP_TILES];
+    if (lane_id() == 0) {
+      a.b.tile_counts_u8[env / TILE] = (uint8_t)__popcll(m);  // every tile slot of the padded table, zeros past the last env
+      s_cmd2[threadIdx.x >> 6] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      reinterpret_cast<float*>(a.b.reset_workspace + padded_tiles(a.n))[blockIdx.x] = (s_cmd2[0] + s_cmd2[1]) + (s_cmd2[2] + s_cmd2[3]);
   }
 }
 
@@ -367,11 +381,51 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
     int64_t level = live ? a.b.terrain_levels[env] : 0;
     q4 hq = bq;       // pose the height scan sees
     f3 hpos = bpos;
+    int64_t k_front = 0;   // flagged envs in front of this tile's group
+    float gnorm_own = 0.f;  // whole-matrix norm of the reset envs' xy commands (:376)
+    const bool last_tile = t == T - 1;
+    if (a.unscanned && (rmask != 0 || last_tile)) {  // (wave-uniform) what the scan / norm launch would have left
+      const int64_t g = t / GROUP_TILES, G = num_groups(a.n);
+      int front = (int)u8_words_partial<WAVE, 2>(a.b.tile_counts_u8, g, lane_id());  // (two chunks in flight: the kernel sits at 124 VGPRs)
+      const float* gp = reinterpret_cast<const float*>(a.b.reset_workspace + padded_tiles(a.n));  // one partial sum per group
+      double acc = 0.0;
+      {  // 16-byte chunks (the slots start at a multiple of four ints: 16-byte aligned), the G % 4 tail by its own lanes
+        const float4* gp4 = reinterpret_cast<const float4*>(gp);
+        const int64_t nq = G / 4;
+        constexpr int U = 2;
+        for (int64_t j0 = lane_id(); j0 < nq; j0 += (int64_t)U * WAVE) {
+          float4 v[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int64_t j = j0 + (int64_t)u * WAVE;
+            v[u] = gp4[j < nq ? j : nq - 1];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+            if (j0 + (int64_t)u * WAVE < nq) acc += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
+        }
+        const int64_t jt = 4 * nq + lane_id();
+        const float tail = gp[jt < G ? jt : 0];
+        acc += jt < G ? (double)tail : 0.0;
+      }
+#pragma unroll
+      for (int off = WAVE / 2; off > 0; off >>= 1) {
+        front += __shfl_xor(front, off, WAVE);
+        acc += __shfl_xor(acc, off, WAVE);
+      }
+      k_front = front;
+      gnorm_own = __builtin_sqrtf((float)acc);
+      if (last_tile && lane_id() == 0) {  // the total, where the scan leaves it (anymal_extras_body reads it)
+        int total = front;
+        for (int64_t tt = g * GROUP_TILES; tt <= t; ++tt) total += tt < t ? a.b.reset_workspace[tt] : __popcll(rmask);
+        a.b.reset_workspace[padded_tiles(a.n) + G] = total;
+      }
+    }
     if (reset) {
       const int64_t g = t / GROUP_TILES;
       const int32_t* tile_counts = a.b.reset_workspace;
       const int32_t* group_offsets = a.b.reset_workspace + padded_tiles(a.n);
-      int64_t k = group_offsets[g];
+      int64_t k = a.unscanned ? k_front : (int64_t)group_offsets[g];
       for (int64_t tt = g * GROUP_TILES; tt < t; ++tt) k += tile_counts[tt];
       k += rank_below(rmask);
       // draws 0..11 dof offset, 12..23 dof vel, 24..25 xy, 26..28 commands; four at a time
@@ -421,7 +475,7 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
       const int64_t type = a.b.terrain_types[env];
       f3 origin{a.b.env_origins[env * 3], a.b.env_origins[env * 3 + 1], a.b.env_origins[env * 3 + 2]};
       if (p.init_done && p.curriculum) {  // update_terrain_level :369-380
-        const float gnorm = a.b.reduce_workspace[T * RW + 0];
+        const float gnorm = a.unscanned ? gnorm_own : a.b.reduce_workspace[T * RW + 0];
         const float dist = norm3(f3{bpos.x - origin.x, bpos.y - origin.y, 0.0f});
         level -= dist < (gnorm * p.max_episode_length_s) * 0.25f ? 1 : 0;
         level += dist > p.half_env_length ? 1 : 0;
@@ -912,6 +966,7 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
                    aligned16(r.dof_pos_out) && aligned16(r.dof_vel_out) && aligned16(b.reset_workspace) &&
                    aligned16(r.noise_u) && aligned16(b.reduce_workspace) && (reinterpret_cast<uintptr_t>(s.base_velocities) & 7u) == 0,
                "anymal: row buffers must be 16-byte aligned (base_velocities 8)");
+  OIGE_REQUIRE(!b.tile_counts_u8 || aligned16(b.tile_counts_u8), "anymal: tile_counts_u8 must be 16-byte aligned");
   OIGE_REQUIRE(params->hs_rows >= 2 && params->hs_cols >= 2 && params->env_rows >= 1 && params->env_cols >= 1,
                "anymal: bad terrain dimensions");
   if (num_envs == 0) return OIGE_OK;
@@ -924,11 +979,14 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
   a.mode = mode;
   hipStream_t st = (hipStream_t)stream;
   const int64_t G = num_groups(num_envs), T = num_tiles(num_envs);
+  a.unscanned = (b.tile_counts_u8 && G <= UNSCANNED_U8_MAX_GROUPS) ? 1 : 0;
   hipLaunchKernelGGL(anymal_flags_kernel, dim3((unsigned)G), dim3(GROUP), 0, st, a);
   if (int rc = check_launch("anymal_flags_kernel")) return rc;
-  hipLaunchKernelGGL(anymal_scan_norm_kernel, dim3(2), dim3(SCAN_THREADS), 0, st, b.reset_workspace, G, padded_tiles(num_envs),
-                     b.reduce_workspace, T);
-  if (int rc = check_launch("anymal_scan_norm_kernel")) return rc;
+  if (!a.unscanned) {
+    hipLaunchKernelGGL(anymal_scan_norm_kernel, dim3(2), dim3(SCAN_THREADS), 0, st, b.reset_workspace, G, padded_tiles(num_envs),
+                       b.reduce_workspace, T);
+    if (int rc = check_launch("anymal_scan_norm_kernel")) return rc;
+  }
   hipLaunchKernelGGL(anymal_head_kernel, dim3((unsigned)T), dim3(WAVE), 0, st, a);
   if (int rc = check_launch("anymal_head_kernel")) return rc;
   if (mode == 0) {  // T scan workgroups + one that folds the extras

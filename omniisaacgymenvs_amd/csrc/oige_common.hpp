@@ -135,29 +135,34 @@ __device__ __forceinline__ int64_t group_rank_unscanned(bool flagged, const int3
 // workgroup reads 4 g bytes instead of 16 g.  The table holds tile_counts_u8_bytes(n) bytes (whole 16-byte chunks).
 __host__ __device__ inline int64_t tile_counts_u8_bytes(int64_t n) { return 16 * ((num_groups(n) + 3) / 4); }
 
-__device__ __forceinline__ int64_t group_rank_unscanned_u8(bool flagged, const uint8_t* counts_u8, int64_t g, int* lds8, int& k0,
-                                                           int& cnt) {
+// This thread's share of the sum of the bytes of words [0, g) of the table, NT threads taking 16-byte chunks in turn.
+template <int NT, int U = 4>
+__device__ __forceinline__ unsigned u8_words_partial(const uint8_t* counts_u8, int64_t g, int tid) {
   const uint4* c4 = reinterpret_cast<const uint4*>(counts_u8);
   const int64_t nq = (g + 3) / 4;  // 16-byte chunks that hold words [0, g)
   unsigned part = 0;
-  constexpr int U = 4;
-  for (int64_t j0 = threadIdx.x; j0 < nq; j0 += (int64_t)U * GROUP) {
+  for (int64_t j0 = tid; j0 < nq; j0 += (int64_t)U * NT) {
     uint4 c[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {  // idle slots re-read a valid chunk (no load inside a conditional block)
-      const int64_t j = j0 + (int64_t)u * GROUP;
+      const int64_t j = j0 + (int64_t)u * NT;
       c[u] = c4[j < nq ? j : nq - 1];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t w0 = 4 * (j0 + (int64_t)u * GROUP);  // first word of the chunk; words >= g belong to this group or later ones
+      const int64_t w0 = 4 * (j0 + (int64_t)u * NT);  // first word of the chunk; words >= g belong to this group or later ones
       part = __builtin_amdgcn_sad_u8(w0 < g ? c[u].x : 0u, 0u, part);  // v_sad_u8: the four bytes of a word summed in one operation
       part = __builtin_amdgcn_sad_u8(w0 + 1 < g ? c[u].y : 0u, 0u, part);
       part = __builtin_amdgcn_sad_u8(w0 + 2 < g ? c[u].z : 0u, 0u, part);
       part = __builtin_amdgcn_sad_u8(w0 + 3 < g ? c[u].w : 0u, 0u, part);
     }
   }
-  int sum = (int)part;
+  return part;
+}
+
+__device__ __forceinline__ int64_t group_rank_unscanned_u8(bool flagged, const uint8_t* counts_u8, int64_t g, int* lds8, int& k0,
+                                                           int& cnt) {
+  int sum = (int)u8_words_partial<GROUP>(counts_u8, g, (int)threadIdx.x);
 #pragma unroll
   for (int off = WAVE / 2; off > 0; off >>= 1) sum += __shfl_xor(sum, off, WAVE);
   const unsigned long long mask = __ballot(flagged);

@@ -227,6 +227,7 @@ class AnymalTerrainTask(RLTask):
         self._reset_bool = torch.zeros(n, dtype=torch.bool, device=dev)
         self._reset_mask = torch.zeros(n, dtype=torch.uint8, device=dev)
         self._reset_workspace = _lib.new_workspace(n, dev)
+        self._tile_counts_u8 = _lib.new_tile_counts_u8(n, dev)
         self._reduce_workspace = torch.zeros((16 + 512) * tiles + 4, **f)  # partial sums + pose records (oige_hip.h)
         self._extras_dev = torch.zeros(len(EPISODE_KEYS) + 1, **f)
         i64 = dict(dtype=torch.int64, device=dev)
@@ -337,6 +338,7 @@ class AnymalTerrainTask(RLTask):
         b.terrain_levels, b.terrain_types = self.terrain_levels.data_ptr(), self.terrain_types.data_ptr()
         b.env_origins, b.extras = self.env_origins.data_ptr(), self._extras_dev.data_ptr()
         b.reset_workspace, b.reduce_workspace = self._reset_workspace.data_ptr(), self._reduce_workspace.data_ptr()
+        b.tile_counts_u8 = self._tile_counts_u8.data_ptr()
         return b
 
     def _reset_io(self, draws=None, noise_u=None, mask=None, push=False) -> _lib.AnymalResetIO:
