@@ -266,7 +266,7 @@ class AnymalBench:
         self.actions = st["actions"]
         self.post_bytes = ANYMAL_POST_BYTES
         self.pre_bytes = lambda resets: 240 * n  # PD torques: R actions, dof_pos, dof_vel + W torques + W actions clone (the resets are in-step, post side)
-        self.kernel = "anymal_head_kernel + anymal_scan_kernel (+ flags / scan / norm / extras: the whole post_physics_step)"
+        self.kernel = "anymal_head_kernel + anymal_scan_kernel (+ flags / extras: the whole post_physics_step)"
         self.workload = (f"AnymalTerrain height-scan obs(188) + 11-term reward + in-step reset + obs noise, {n} envs per GPU, "
                          "synthetic state, 1200x2000 int16 heightfield")
         self.extra_cfg = {"scan_points": 140, "decimation_substeps_timed": 1}
