@@ -291,3 +291,35 @@ def test_height_min_table_is_the_reference_minimum_and_changes_nothing():
             assert task._height_min_table() is not None and task._height_min_key[0] is task.height_samples
     for a, b, what in zip(outs[0], outs[1], ("obs_buf", "rew_buf", "reset_buf")):
         assert_equal(a, b, what)
+
+
+@pytest.mark.parametrize("n", [257, 5000, 262144])
+def test_step_without_the_scan_launch_equals_the_step_with_it(n):
+    """With oige_anymal_buffers.tile_counts_u8 the head kernel's waves derive their offset in the id list and the command norm
+    themselves (no scan + norm launch); NULL keeps the launch.  Same ids, rows, terrain levels and observations, two steps."""
+    outs = []
+    for with_u8 in (True, False):
+        env, task, st = _loaded(n)
+        task._anymals.apply_resets = False
+        if not with_u8:
+            inner = task._buffers
+
+            def no_u8(inner=inner):
+                b = inner()
+                b.tile_counts_u8 = None
+                return b
+
+            task._buffers = no_u8
+        got = []
+        for _ in range(2):
+            task.post_physics_step()
+            torch.cuda.synchronize()
+            o = task._reset_out
+            k = int(o["count"].item())
+            assert k > 0
+            got += [o["env_ids"][:k].clone(), o["base_pos"][:k].clone(), o["dof_pos"][:k].clone(), task.terrain_levels.clone(),
+                    task.env_origins.clone(), task.commands.clone(), task.obs_buf.clone(), task.rew_buf.clone(),
+                    task.reset_buf.clone(), task.progress_buf.clone(), task.extras["episode"]["terrain_level"].clone()]
+        outs.append(got)
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
