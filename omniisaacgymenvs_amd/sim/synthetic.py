@@ -145,7 +145,14 @@ class SyntheticArticulationView:
         self._scatter(self.joint_positions, positions, indices, count)
 
     def set_joint_velocities(self, velocities: Tensor, indices=None, count=None) -> None:
-        self._scatter(self.joint_velocities, velocities, indices, count)
+        if (self.apply_resets is False and count is None and (indices is None or indices.shape[0] == self.count)
+                and velocities.shape == self.joint_velocities.shape):
+            # benchmark mode, all envs (ingenuity.py:240, crazyflie.py:258: the rotor spin of every env, every step): keep a
+            # reference, as set_joint_position_targets does -- the N*D copy is the PhysX stand-in's work, not the task's
+            # (a 6 us launch and its gap per step at 1 M envs, a tenth of Ingenuity's step)
+            self.joint_velocities = velocities
+        else:
+            self._scatter(self.joint_velocities, velocities, indices, count)
 
     def set_joint_efforts(self, efforts: Tensor, indices=None, count=None) -> None:
         # the common case (all envs, arange indices) keeps a reference instead of copying N*D floats

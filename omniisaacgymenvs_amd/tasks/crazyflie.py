@@ -242,7 +242,7 @@ class CrazyflieTask(RLTask):
             flags |= _lib.PRE_COUNTS_VALID
         if self.clamp_actions_in_kernel:
             flags |= _lib.PRE_CLAMP_ACTIONS
-        self._noise4 = (0.01 * torch.randn(4, dtype=torch.float32, device=self._device)).contiguous()  # :197
+        self._noise4.normal_(0.0, 0.01)  # 0.01 * torch.randn(4) (:197): the same four draws, scaled inside the one launch
         self.root_pos, self.root_rot = self._copters.get_world_poses(clone=False)
         p, b, r = self._params(), self._buffers(), self._reset_io()
         rc = _lib.load().oige_crazyflie_pre_physics(C.byref(p), actions.data_ptr(), self.root_rot.data_ptr(), C.byref(b), C.byref(r),
