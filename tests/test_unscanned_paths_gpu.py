@@ -49,6 +49,7 @@ def test_step_is_the_same_without_the_byte_table(name, n):
     for step in range(3):
         act = (torch.rand(n, a.task.num_actions, generator=g) * 2 - 1).to("cuda:0")
         for t in (a.task, b.task):
+            torch.manual_seed(100 + step)  # (tasks that draw from torch's generator see the same stream)
             t.pre_physics_step(act)
             t.post_physics_step()
         torch.cuda.synchronize()
