@@ -957,6 +957,8 @@ def main() -> None:
     ap.add_argument("--reset-frac", type=float, default=None,
                     help="second workload: only this fraction of the envs terminates per step (0.001 = the reference's steady "
                          "state, about N/1000 resets per step, SURVEY.md a8); default: the r01 workload, 13-25 %% per step")
+    ap.add_argument("--event-every", type=int, default=int(os.environ.get("OIGE_BENCH_EVENT_EVERY", "4")),
+                    help="HIP-event brackets around pre / post on every k-th timed step (1: every step, as r01 / r02 did)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="PMC-derived HBM bytes per launch of the dominant kernel (profiles/run_profiles.sh) -> roofline.traffic")
     args = ap.parse_args()
@@ -982,16 +984,26 @@ def main() -> None:
 
     # HIP events around the post kernel of every timed step.  They are CREATED here: hipEventCreate inside the loop costs
     # ~100 us per step (measured), recording a ready-made one does not.
-    if dry:
-        class _NoEvent:
-            def record(self):
-                pass
+    class _NoEvent:
+        def record(self):
+            pass
 
+    if dry:
         ev_pairs = [(_NoEvent(), _NoEvent()) for _ in range(args.steps)]
         ev_start = [_NoEvent() for _ in range(args.steps)]
     else:
         ev_pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         ev_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        # Three event records per step cost 16 us of GPU idle time per step (a 10 us hole between post and the next pre, 6 us
+        # between pre and post: profiles/r03/step_gaps_Ant.txt; without them consecutive kernels start 0.0-0.1 us apart), 12 %
+        # of Ant's step.  So the per-kernel brackets are taken on every `--event-every`-th step of the timed region and the
+        # span from the first step's first launch to the last step's last kernel.
+        every = 1 if os.environ.get("OIGE_BENCH_DUMP_STEPS") else max(1, args.event_every)
+        if every != 1:
+            for i in range(args.steps):
+                if i % every:
+                    ev_pairs[i] = (_NoEvent() if i else ev_pairs[i][0], _NoEvent() if i + 1 < args.steps else ev_pairs[i][1])
+                    ev_start[i] = _NoEvent() if i else ev_start[i]
     after = getattr(bench, "after_post", lambda: None)
     if args.graph:
         if hasattr(bench, "after_post"):  # HandBench: noise arguments per call, wrapper-side leg
@@ -1056,13 +1068,16 @@ def main() -> None:
     t = bench.task
     job_stats = od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
 
+    timed = []
     if dry:
         post_ms = pre_ms = gpu_span_ms = None
     elif args.graph:  # the kernels are nodes of one graph: the whole replayed step stands in for the post kernel (a lower bound)
         post_ms, pre_ms = ev_start[0].elapsed_time(ev_pairs[-1][1]) / len(ev_pairs), None
     else:
-        post_ms = sum(a.elapsed_time(b) for a, b in ev_pairs) / len(ev_pairs)
-        pre_ms = sum(es.elapsed_time(e0) for es, (e0, _) in zip(ev_start, ev_pairs)) / len(ev_pairs)
+        timed = [(es, e0, e1) for es, (e0, e1) in zip(ev_start, ev_pairs)
+                 if not any(isinstance(e, _NoEvent) for e in (es, e0, e1))]
+        post_ms = sum(a.elapsed_time(b) for _, a, b in timed) / max(1, len(timed))
+        pre_ms = sum(es.elapsed_time(e0) for es, e0, _ in timed) / max(1, len(timed))
     if not dry:
         gpu_span_ms = ev_start[0].elapsed_time(ev_pairs[-1][1]) / len(ev_pairs)  # first pre launch -> last post end, per step
         if os.environ.get("OIGE_BENCH_DUMP_STEPS") and not args.graph:  # per-step (pre, post, gap to the next step) in us, to stderr
@@ -1122,6 +1137,7 @@ def main() -> None:
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "algorithmic_bytes_per_env": bench.post_bytes, "avg_kernel_ms": post_ms,
                 "pre_physics_ms": pre_ms, "gpu_ms_per_step": gpu_span_ms,
+                "event_brackets": f"every {max(1, args.event_every)}. timed step ({len(timed)} of {args.steps})",
                 "measured_copy_gbs": copy_gbs,
                 "frac_of_measured_copy_12_streams": achieved / copy_gbs["streams_12"],
             }

@@ -313,11 +313,8 @@ struct LocoPre {
   uint32_t flags;
 };
 
-// reset_idx for env `i` landing in compacted row `k` (locomotion.py:133-158)
-// STAGE: the DOF rows go to the caller instead of HBM (dof_pos into the LDS row `stage_pos`, dof_vel into `qv_out`), which then
-// writes the group's compacted rows as one lane-linear run
-// the rows reset_idx reads for env i: fetched apart from the arithmetic so that a caller can issue them with its other loads
-// (a load issued after a store waits for that store's round trip: loads and stores share one in-order counter)
+// the rows reset_idx reads for env i (locomotion.py:133-158), fetched apart from the arithmetic so that a caller can issue them
+// together
 template <int D>
 struct ResetRow {
   float dof0[D];
@@ -336,12 +333,9 @@ __device__ __forceinline__ ResetRow<D> reset_load(const oige_locomotion_reset_io
   return w;
 }
 
-template <int D, bool STAGE = false>
-__device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const oige_locomotion_buffers& b,
-                                          const oige_locomotion_reset_io& r, const ResetRow<D>& w, int64_t i, int64_t k,
-                                          float* __restrict__ stage_pos = nullptr, float* __restrict__ qv_out = nullptr) {
-  // the 2*D uniform draws: [0,D) -> dof_pos (1st torch.rand, :137), [D,2D) -> dof_vel (2nd, :139)
-  float u[2 * D];
+// the 2*D uniform draws of reset_idx for env i / compacted row k: [0,D) -> dof_pos (1st torch.rand, :137), [D,2D) -> dof_vel (2nd, :139)
+template <int D>
+__device__ __forceinline__ void reset_draws(const oige_locomotion_reset_io& r, int64_t i, int64_t k, float (&u)[2 * D]) {
   if (r.u_pos != nullptr) {
 #pragma unroll
     for (int j = 0; j < D; ++j) {
@@ -360,21 +354,36 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
         if (4 * blk + q < 2 * D) u[4 * blk + q] = u01(w[q]);
     }
   }
-  float qp[D], qv[D];
+}
+
+// the DOF rows of reset_idx (:137-139) from the draws
+template <int D>
+__device__ __forceinline__ void reset_dof_rows(const oige_locomotion_params& p, const float (&dof0)[D], const float (&u)[2 * D],
+                                               float (&qp)[D], float (&qv)[D]) {
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     // torch_rand_float(lo, hi): (hi - lo) * u + lo, with hi - lo folded in double first (:137,:139)
     const float dp = 0.4f * u[j] + (-0.2f);
-    qp[j] = tensor_clamp(w.dof0[j] + dp, p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :138
+    qp[j] = tensor_clamp(dof0[j] + dp, p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :138
     qv[j] = 0.2f * u[D + j] + (-0.1f);
   }
-  if (STAGE) {
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-      stage_pos[j] = qp[j];
-      qv_out[j] = qv[j];
-    }
-  } else if (D % 4 == 0 && aligned16(r.dof_pos_out) && aligned16(r.dof_vel_out)) {  // whole rows as 16-byte stores
+}
+
+// prev_potentials[i] = potentials[i] of a reset env (:151-154)
+__device__ __forceinline__ float reset_potential(const oige_locomotion_params& p, const float (&ip)[3]) {
+  const f3 tt{p.target[0] - ip[0], p.target[1] - ip[1], 0.0f};  // :151-152
+  return (-norm3(tt)) / p.dt;                                   // :153
+}
+
+// reset_idx for env `i` landing in compacted row `k` (locomotion.py:133-158): everything, one env per thread (the reference-flow
+// entry point oige_locomotion_reset_idx; the pre kernel below splits the same work over natural and dense lanes)
+template <int D>
+__device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const oige_locomotion_buffers& b,
+                                          const oige_locomotion_reset_io& r, const ResetRow<D>& w, int64_t i, int64_t k) {
+  float u[2 * D], qp[D], qv[D];
+  reset_draws<D>(r, i, k, u);
+  reset_dof_rows<D>(p, w.dof0, u, qp, qv);
+  if (D % 4 == 0 && aligned16(r.dof_pos_out) && aligned16(r.dof_vel_out)) {  // whole rows as 16-byte stores
 #pragma unroll
     for (int c = 0; c < D / 4; ++c) {
       reinterpret_cast<float4*>(r.dof_pos_out + k * D)[c] = make_float4(qp[4 * c], qp[4 * c + 1], qp[4 * c + 2], qp[4 * c + 3]);
@@ -388,15 +397,13 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
     }
   }
   const float* ip = w.ip;
-  const float4 iq = w.iq;
   r.root_pos_out[k * 3 + 0] = ip[0];
   r.root_pos_out[k * 3 + 1] = ip[1];
   r.root_pos_out[k * 3 + 2] = ip[2];
-  *reinterpret_cast<float4*>(r.root_rot_out + k * 4) = iq;
+  *reinterpret_cast<float4*>(r.root_rot_out + k * 4) = w.iq;
 #pragma unroll
   for (int c = 0; c < 6; ++c) r.root_vel_out[k * 6 + c] = 0.0f;  // :142
-  const f3 tt{p.target[0] - ip[0], p.target[1] - ip[1], 0.0f};   // :151-152
-  const float pot = (-norm3(tt)) / p.dt;                         // :153
+  const float pot = reset_potential(p, w.ip);
   b.prev_potentials[i] = pot;
   b.potentials[i] = pot;  // :154
   b.reset_buf[i] = 0;     // :157
@@ -404,115 +411,240 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
   r.env_ids[k] = i;
 }
 
+// One pass over the byte table (oige_common.hpp: tile_counts_u8): up to UNSCANNED_U8_MAX_GROUPS groups the four 16-byte chunks
+// a thread takes cover every word in front of any group, so the loads are issued in one go with the kernel's other loads and
+// summed when they have arrived (u8_words_partial's loop puts a full wait inside its body).
+static_assert(UNSCANNED_U8_MAX_GROUPS <= 4 * 4 * GROUP, "one pass of four chunks per thread must cover the table");
+struct U8Prefix {
+  uint4 c[4];
+};
+__device__ __forceinline__ U8Prefix u8_prefix_issue(const uint8_t* counts_u8, int64_t g, int tid) {
+  const uint4* c4 = reinterpret_cast<const uint4*>(counts_u8);
+  const int nq = (int)((g + 3) / 4);  // chunks that hold words [0, g)
+  U8Prefix p;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {  // idle slots re-read a valid chunk: no load inside a conditional block
+    const int j = tid + u * GROUP;
+    p.c[u] = c4[j < nq ? j : (nq > 0 ? nq - 1 : 0)];
+  }
+  return p;
+}
+__device__ __forceinline__ int u8_prefix_sum(const U8Prefix& p, int64_t g, int tid) {
+  unsigned part = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t w0 = 4 * (int64_t)(tid + u * GROUP);  // first word of the chunk; words >= g belong to this group or later ones
+    part = __builtin_amdgcn_sad_u8(w0 < g ? p.c[u].x : 0u, 0u, part);
+    part = __builtin_amdgcn_sad_u8(w0 + 1 < g ? p.c[u].y : 0u, 0u, part);
+    part = __builtin_amdgcn_sad_u8(w0 + 2 < g ? p.c[u].z : 0u, 0u, part);
+    part = __builtin_amdgcn_sad_u8(w0 + 3 < g ? p.c[u].w : 0u, 0u, part);
+  }
+  return wave_sum((int)part);
+}
+
+// pre_physics_step of one 256-env group.  A workgroup's life is a chain of memory round trips (microseconds each under
+// load), and the kernel's rate is resident workgroups x bytes per workgroup / that lifetime, so the chain is kept to TWO:
+//   trip 1  the reset flags, the tile counts in front of the group and the action quads, issued together, nothing
+//           conditional (idle lanes re-read a valid element);
+//   then    rank of the flagged envs; forces / clone stores and the flags' own zeroing (natural lanes, coalesced);
+//           groups without a flagged env end here;
+//   trip 2  the reset rows of the group's flagged envs on DENSE lanes (thread j takes the j-th flagged env: a wave with a
+//           few flagged lanes would run the Philox draws for all 64), overlapping the acknowledgement of the stores above;
+//   then    the compacted output rows, staged in LDS and written as contiguous runs.
 // SCANNED: the group offsets are in the workspace (scan_groups_kernel ran in front).  Otherwise the workgroup derives its
-// offset from the tile counts itself (group_rank_unscanned): one launch and one launch gap less per step, for 8 g bytes of
-// L2 reads per workgroup -- quadratic in the env count, so the host picks it up to LOCO_UNSCANNED_MAX_GROUPS groups
-// (Humanoid at 512 K envs: step 130.5 -> 126.8 us; Ant at 1 M envs: pre kernel 36 -> 43 us, no gain, keeps the scan).
+// offset from the tile counts itself: from the int32 counts (group_rank_unscanned, up to LOCO_UNSCANNED_MAX_GROUPS groups)
+// or from their byte twin (up to UNSCANNED_U8_MAX_GROUPS).
 constexpr int64_t LOCO_UNSCANNED_MAX_GROUPS = 2048;
-// With the byte twin of the tile counts (oige_locomotion_buffers.tile_counts_u8) the prefix reads are a quarter: up to
-// UNSCANNED_U8_MAX_GROUPS groups (oige_common.hpp).
+// Forces and clone are written once: streaming stores.  The actions are read with a PLAIN load: the policy has just written
+// them, and a 32 MB tensor that recent is still in the memory-side cache, which a non-temporal load does not use (Ant, 1 M
+// envs: pre kernel 37.3 -> 34.1 us; profiles/r03/pre_variants.txt).  -DOIGE_LOCO_PRE_NT_LD / _PLAIN_{FORCES,CLONE}: A/B builds
+__device__ __forceinline__ float4 pre_ld4(const float* p) {
+#ifndef OIGE_LOCO_PRE_NT_LD
+  return *reinterpret_cast<const float4*>(p);
+#else
+  return ld4_stream(p);
+#endif
+}
+__device__ __forceinline__ void pre_st4_forces(float* p, const float4 t) {
+#ifdef OIGE_LOCO_PRE_PLAIN_FORCES
+  *reinterpret_cast<float4*>(p) = t;
+#else
+  st4_stream(p, t);
+#endif
+}
+__device__ __forceinline__ void pre_st4_clone(float* p, const float4 t) {
+#ifdef OIGE_LOCO_PRE_PLAIN_CLONE
+  *reinterpret_cast<float4*>(p) = t;
+#else
+  st4_stream(p, t);
+#endif
+}
 template <int D, int RANK>
 __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) {
+  constexpr int NF4 = GROUP * D / 4;  // float4 pieces of a full group's action run
+  constexpr int ITS = (NF4 + GROUP - 1) / GROUP;
+#ifdef OIGE_LOCO_PRE_STAGE_ALL  // A/B builds (profiles/r03/pre_variants.txt)
+  constexpr bool STAGE = true;
+#else
+  constexpr bool STAGE = (D % 4) != 0;  // rows that are whole float4s are contiguous across dense lanes as they are
+#endif
   __shared__ int lds8[2 * GROUP_TILES];
   __shared__ int s_list[GROUP];
+  __shared__ __align__(16) float s_gear[(D + 3) / 4 * 4];
+  __shared__ __align__(16) float s_rows[STAGE ? GROUP * D : 4];
+  __shared__ float s_pos3[GROUP * 3];
+  const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
-  const int64_t env = g * GROUP + threadIdx.x;
   const int64_t G = num_groups(a.n);
-
-  // Order: every load of the workgroup first (the reset flag, the tile counts in front of the group, the action quads, and
-  // - after the flagged envs are ranked - the reset rows), then every store: a load issued behind a store waits for that
-  // store's round trip.
-  const bool flagged = env < a.n && a.b.reset_buf[env] != 0;
-
-  // forces = actions * joint_gears * power_scale (:125-126), lane-linear over the group's
-  // contiguous 256*D floats; optional clamp (vec_env_rlgames.py:77) and clone (:125)
-  const int64_t base = g * GROUP * D;
+  const int64_t env = g * GROUP + tid;
+  const int64_t base = g * GROUP * D;  // the group's contiguous run of 256*D floats; a multiple of D and of 4
   const int64_t total = a.n * D;
-  constexpr int NF4 = GROUP * D / 4;
-  constexpr int ITS = (NF4 + GROUP - 1) / GROUP;
+  const bool full = (g + 1) * GROUP <= a.n;
+
+  // ---- trip 1
+  const int64_t flag_raw = a.b.reset_buf[env < a.n ? env : a.n - 1];
+  U8Prefix pre;
+  if (RANK == RANK_U8) pre = u8_prefix_issue(a.b.tile_counts_u8, g, tid);
   float v[ITS][4];
+  if (full) {
 #pragma unroll
-  for (int it = 0; it < ITS; ++it) {
-    const int f = it * GROUP + threadIdx.x;
-    const int64_t e = base + 4 * (int64_t)f;
+    for (int it = 0; it < ITS; ++it) {
+      const int f = it * GROUP + tid;
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (NF4 % GROUP == 0 || f < NF4) t = pre_ld4(a.actions_in + base + 4 * (int64_t)f);
+      v[it][0] = t.x; v[it][1] = t.y; v[it][2] = t.z; v[it][3] = t.w;
+    }
+  } else {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[it][k] = 0.f;
-    if (f < NF4 && e < total) {
-      if (e + 3 < total) {
-        const float4 t = *reinterpret_cast<const float4*>(a.actions_in + e);
-        v[it][0] = t.x; v[it][1] = t.y; v[it][2] = t.z; v[it][3] = t.w;
-      } else {
-        for (int k = 0; k < 4; ++k)
-          if (e + k < total) v[it][k] = a.actions_in[e + k];
-      }
+    for (int it = 0; it < ITS; ++it) {
+      const int64_t e = base + 4 * (int64_t)(it * GROUP + tid);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[it][k] = e + k < total ? a.actions_in[e + k] : 0.f;
     }
   }
+  {  // joint_gears -> LDS: compile-time indices keep the argument reads scalar (a run-time index into a kernel-argument
+     // array is a VECTOR load from the argument block)
+    float gj = 0.f;
+#pragma unroll
+    for (int j = 0; j < D; ++j) gj = tid == j ? a.p.joint_gears[j] : gj;
+    if (tid < (D + 3) / 4 * 4) s_gear[tid] = gj;
+  }
 
-  // compaction rank of the flagged envs (:121-123).  The flagged envs of the group are first packed
-  // into LDS so that the reset runs on DENSE lanes (thread j takes the group's j-th flagged env): with a few
-  // flagged lanes per wave the divergent version spent 4 waves' worth of issue slots on ~10 % of the lanes, and
-  // consecutive lanes now write consecutive compacted rows.
+  // ---- compaction rank of the flagged envs (:121-123)
+  const bool flagged = env < a.n && flag_raw != 0;
   int k0, cnt;
   int64_t k;
-  k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
-  if (flagged) s_list[(int)(k - k0)] = (int)threadIdx.x;
-  __syncthreads();
-  const bool mine = (int)threadIdx.x < cnt;
-  const int64_t my_env = g * GROUP + (mine ? s_list[threadIdx.x] : 0);
-  ResetRow<D> row;
-  if (mine) row = reset_load<D>(a.r, my_env);
+  if (RANK == RANK_U8) {
+    const int front = u8_prefix_sum(pre, g, tid);
+    const unsigned long long mask = __ballot(flagged);
+    const int w = tid >> 6;
+    if (lane_id() == 0) {
+      lds8[w] = __popcll(mask);
+      lds8[GROUP_TILES + w] = front;
+    }
+    __syncthreads();
+    int before = 0;
+    k0 = 0;
+    cnt = 0;
+#pragma unroll
+    for (int i = 0; i < GROUP_TILES; ++i) {
+      before += (i < w) ? lds8[i] : 0;
+      cnt += lds8[i];
+      k0 += lds8[GROUP_TILES + i];
+    }
+    k = flagged ? (int64_t)k0 + before + rank_below(mask) : -1;
+  } else {
+    k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
+  }
+  if (flagged) s_list[(int)(k - k0)] = tid;
 
+  // ---- forces = actions * joint_gears * power_scale (:125-126), lane-linear over the group's run; optional clamp
+  // (vec_env_rlgames.py:77) and clone (:125).  s_gear is visible: the rank's barrier sits behind its writes.
 #pragma unroll
   for (int it = 0; it < ITS; ++it) {
-    const int f = it * GROUP + threadIdx.x;
+    const int f = it * GROUP + tid;
     const int64_t e = base + 4 * (int64_t)f;
-    if (f >= NF4 || e >= total) break;
+    if (NF4 % GROUP != 0 && f >= NF4) break;
     float fo[4];
+    int col = (4 * f) % D;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (a.flags & OIGE_PRE_CLAMP_ACTIONS) v[it][k] = clamp_sym(v[it][k], a.p.clip_actions);
-      const int col = (4 * f + k) % D;  // the group's run starts at a multiple of D
-      fo[k] = (v[it][k] * a.p.joint_gears[col]) * a.p.power_scale;
+    for (int q = 0; q < 4; ++q) {
+      if (a.flags & OIGE_PRE_CLAMP_ACTIONS) v[it][q] = clamp_sym(v[it][q], a.p.clip_actions);
+      fo[q] = (v[it][q] * s_gear[col]) * a.p.power_scale;
+      if (++col == D) col = 0;
     }
-    if (e + 3 < total) {
-      if (a.actions_out) *reinterpret_cast<float4*>(a.actions_out + e) = make_float4(v[it][0], v[it][1], v[it][2], v[it][3]);
-      *reinterpret_cast<float4*>(a.forces_out + e) = make_float4(fo[0], fo[1], fo[2], fo[3]);
+    if (full) {
+      if (a.actions_out) pre_st4_clone(a.actions_out + e, make_float4(v[it][0], v[it][1], v[it][2], v[it][3]));
+      pre_st4_forces(a.forces_out + e, make_float4(fo[0], fo[1], fo[2], fo[3]));
     } else {
-      for (int k = 0; k < 4; ++k)
-        if (e + k < total) {
-          if (a.actions_out) a.actions_out[e + k] = v[it][k];
-          a.forces_out[e + k] = fo[k];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (e + q < total) {
+          if (a.actions_out) a.actions_out[e + q] = v[it][q];
+          a.forces_out[e + q] = fo[q];
         }
     }
   }
+  if (flagged) {  // natural lanes: consecutive lanes, consecutive flags
+    a.b.reset_buf[env] = 0;     // :157
+    a.b.progress_buf[env] = 0;  // :158
+  }
+  if (g == G - 1 && tid == 0) *a.r.count = (int64_t)k0 + cnt;
+  if (cnt == 0) return;  // uniform over the workgroup
+#ifdef OIGE_LOCO_PRE_NO_RESET  // timing-only build
+  return;
+#endif
+  __syncthreads();       // s_list
 
-  // reset of the flagged envs.
-  // Rows that are not a whole number of float4 (Humanoid: 21 floats) would leave each lane walking its own 84-byte row with
-  // scalar stores; the group's compacted rows are ONE contiguous run of cnt * D floats, so they are staged through LDS and
-  // written lane-linearly, dof_pos then dof_vel through the same buffer (Ant's 32-byte rows are two float4 per lane, already
-  // contiguous across lanes).
-  constexpr bool STAGE = (D % 4) != 0;
-  __shared__ float s_rows[STAGE ? GROUP * D : 1];
-  if (!STAGE) {
-    if (mine) reset_env<D>(a.p, a.b, a.r, row, my_env, (int64_t)k0 + threadIdx.x);
-  } else if (cnt > 0) {  // cnt is uniform over the workgroup: the barriers below are reached by all of it or none
-    float qv[D];
-    if (mine)
-      reset_env<D, true>(a.p, a.b, a.r, row, my_env, (int64_t)k0 + threadIdx.x, s_rows + threadIdx.x * D, qv);
-    __syncthreads();
+  // ---- trip 2: reset_idx of the flagged envs on dense lanes (:133-158)
+  const bool mine = tid < cnt;
+  const int64_t kk = (int64_t)k0 + tid;
+  float qv[D];
+  if (mine) {
+    const int64_t i = g * GROUP + s_list[tid];
+    const ResetRow<D> w = reset_load<D>(a.r, i);
+    float u[2 * D], qp[D];
+    reset_draws<D>(a.r, i, kk, u);
+    reset_dof_rows<D>(a.p, w.dof0, u, qp, qv);
+    const float pot = reset_potential(a.p, w.ip);
+    a.b.prev_potentials[i] = pot;
+    a.b.potentials[i] = pot;  // :154
+    a.r.env_ids[kk] = i;
+    *reinterpret_cast<float4*>(a.r.root_rot_out + kk * 4) = w.iq;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) s_pos3[tid * 3 + c] = w.ip[c];
+    if (STAGE) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) s_rows[tid * D + j] = qp[j];
+    } else {
+#pragma unroll
+      for (int c = 0; c < D / 4; ++c) {
+        reinterpret_cast<float4*>(a.r.dof_pos_out + kk * D)[c] = make_float4(qp[4 * c], qp[4 * c + 1], qp[4 * c + 2], qp[4 * c + 3]);
+        reinterpret_cast<float4*>(a.r.dof_vel_out + kk * D)[c] = make_float4(qv[4 * c], qv[4 * c + 1], qv[4 * c + 2], qv[4 * c + 3]);
+      }
+    }
+  }
+  __syncthreads();
+  // the group's compacted rows are contiguous runs: root_pos (cnt x 3), root_vel (cnt x 6 zeros, :142), the DOF rows
+  {
+    float* dst = a.r.root_pos_out + (int64_t)k0 * 3;
+    for (int e = tid; e < cnt * 3; e += GROUP) dst[e] = s_pos3[e];
+    float2* z = reinterpret_cast<float2*>(a.r.root_vel_out + (int64_t)k0 * 6);  // 24-byte rows: 8-byte aligned
+    for (int e = tid; e < cnt * 3; e += GROUP) z[e] = make_float2(0.f, 0.f);
+  }
+  if (STAGE) {
     const int run = cnt * D;
     float* dst = a.r.dof_pos_out + (int64_t)k0 * D;
-    for (int e = threadIdx.x; e < run; e += GROUP) dst[e] = s_rows[e];
+    for (int e = tid; e < run; e += GROUP) dst[e] = s_rows[e];
     __syncthreads();
     if (mine) {
 #pragma unroll
-      for (int j = 0; j < D; ++j) s_rows[threadIdx.x * D + j] = qv[j];
+      for (int j = 0; j < D; ++j) s_rows[tid * D + j] = qv[j];
     }
     __syncthreads();
     dst = a.r.dof_vel_out + (int64_t)k0 * D;
-    for (int e = threadIdx.x; e < run; e += GROUP) dst[e] = s_rows[e];
+    for (int e = tid; e < run; e += GROUP) dst[e] = s_rows[e];
   }
-  if (g == G - 1 && threadIdx.x == 0) *a.r.count = (int64_t)k0 + cnt;
 }
 
 template <int D>
@@ -591,6 +723,7 @@ static int check_reset_io(const oige_locomotion_reset_io* r) {
                    r->root_vel_out,
                "locomotion: null reset output pointer");
   OIGE_REQUIRE(aligned16(r->initial_root_rot) && aligned16(r->root_rot_out), "locomotion: (N,4) buffers must be 16-byte aligned");
+  OIGE_REQUIRE((reinterpret_cast<uintptr_t>(r->root_vel_out) & 7u) == 0, "locomotion: root_vel_out must be 8-byte aligned");
   return OIGE_OK;
 }
 
@@ -676,6 +809,8 @@ int oige_locomotion_pre_physics(const oige_locomotion_params* params, const floa
   OIGE_REQUIRE(!b.tile_counts_u8 || aligned16(b.tile_counts_u8), "locomotion_pre_physics: tile_counts_u8 must be 16-byte aligned");
   OIGE_REQUIRE(aligned16(actions_in) && aligned16(forces_out) && aligned16(actions_out) && aligned16(b.reset_workspace),
                "locomotion_pre_physics: actions/forces/workspace must be 16-byte aligned");
+  OIGE_REQUIRE(params->num_dof % 4 != 0 || (aligned16(reset_io->dof_pos_out) && aligned16(reset_io->dof_vel_out)),
+               "locomotion_pre_physics: dof_pos_out/dof_vel_out must be 16-byte aligned");
   LocoPre a;
   a.p = *params;
   a.b = b;
