@@ -479,7 +479,7 @@ __device__ __forceinline__ void pre_st4_clone(float* p, const float4 t) {
   st4_stream(p, t);
 #endif
 }
-template <int D, int RANK>
+template <int D, int RANK, int PART = 0>  // PART (A/B builds): 0 the whole step, 1 forces / clone only, 2 compaction + resets only
 __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) {
   constexpr int NF4 = GROUP * D / 4;  // float4 pieces of a full group's action run
   constexpr int ITS = (NF4 + GROUP - 1) / GROUP;
@@ -492,7 +492,6 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
   __shared__ int s_list[GROUP];
   __shared__ __align__(16) float s_gear[(D + 3) / 4 * 4];
   __shared__ __align__(16) float s_rows[STAGE ? GROUP * D : 4];
-  __shared__ float s_pos3[GROUP * 3];
   const int tid = threadIdx.x;
   const int64_t g = blockIdx.x;
   const int64_t G = num_groups(a.n);
@@ -502,11 +501,12 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
   const bool full = (g + 1) * GROUP <= a.n;
 
   // ---- trip 1
-  const int64_t flag_raw = a.b.reset_buf[env < a.n ? env : a.n - 1];
+  const int64_t flag_raw = PART == 1 ? 0 : a.b.reset_buf[env < a.n ? env : a.n - 1];
   U8Prefix pre;
-  if (RANK == RANK_U8) pre = u8_prefix_issue(a.b.tile_counts_u8, g, tid);
+  if (RANK == RANK_U8 && PART != 1) pre = u8_prefix_issue(a.b.tile_counts_u8, g, tid);
   float v[ITS][4];
-  if (full) {
+  if (PART == 2) {
+  } else if (full) {
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
       const int f = it * GROUP + tid;
@@ -532,9 +532,11 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
 
   // ---- compaction rank of the flagged envs (:121-123)
   const bool flagged = env < a.n && flag_raw != 0;
-  int k0, cnt;
-  int64_t k;
-  if (RANK == RANK_U8) {
+  int k0 = 0, cnt = 0;
+  int64_t k = -1;
+  if (PART == 1) {
+    __syncthreads();
+  } else if (RANK == RANK_U8) {
     const int front = u8_prefix_sum(pre, g, tid);
     const unsigned long long mask = __ballot(flagged);
     const int w = tid >> 6;
@@ -557,11 +559,34 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
     k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   }
   if (flagged) s_list[(int)(k - k0)] = tid;
+  if (PART != 1 && g == G - 1 && tid == 0) *a.r.count = (int64_t)k0 + cnt;
+  __syncthreads();  // s_list (and s_gear, for a workgroup that took the scanned rank)
+
+  // ---- trip 2, issued IN FRONT of the stores below (loads and stores share one in-order counter: behind them, the wait for
+  // these rows would also be the wait for the stores' acknowledgement).  Wave w takes the group's dense rows [64 w, 64 w + 64):
+  // thread j of it the (64 w + j)-th flagged env, so a wave with a few flagged lanes does not run the Philox draws for all 64.
+  // Nothing conditional: idle lanes re-read the group's first env (one request for all of them).
+  const int w = tid >> 6, lane = lane_id();
+  const int row0 = WAVE * w;
+  const int nw = cnt - row0 < 0 ? 0 : (cnt - row0 > WAVE ? WAVE : cnt - row0);  // dense rows of this wave
+  const bool mine = lane < nw;
+  const int64_t di = g * GROUP + (mine ? s_list[row0 + lane] : 0);
+  const int64_t kk = (int64_t)k0 + row0 + lane;
+  ResetRow<D> row;
+  if (PART != 1) row = reset_load<D>(a.r, di);
+  float u[2 * D];
+  if (PART != 1 && a.r.u_pos != nullptr) {  // the reference-flow tables: (count, D), so idle lanes may not touch them
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      u[j] = mine ? a.r.u_pos[kk * D + j] : 0.f;
+      u[D + j] = mine ? a.r.u_vel[kk * D + j] : 0.f;
+    }
+  }
 
   // ---- forces = actions * joint_gears * power_scale (:125-126), lane-linear over the group's run; optional clamp
-  // (vec_env_rlgames.py:77) and clone (:125).  s_gear is visible: the rank's barrier sits behind its writes.
+  // (vec_env_rlgames.py:77) and clone (:125)
 #pragma unroll
-  for (int it = 0; it < ITS; ++it) {
+  for (int it = 0; it < (PART == 2 ? 0 : ITS); ++it) {
     const int f = it * GROUP + tid;
     const int64_t e = base + 4 * (int64_t)f;
     if (NF4 % GROUP != 0 && f >= NF4) break;
@@ -589,34 +614,25 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
     a.b.reset_buf[env] = 0;     // :157
     a.b.progress_buf[env] = 0;  // :158
   }
-  if (g == G - 1 && tid == 0) *a.r.count = (int64_t)k0 + cnt;
-  if (cnt == 0) return;  // uniform over the workgroup
+  // A wave without a dense row ends here: its slots go to the next workgroup while the dense wave(s) finish (no barrier below).
+  if (nw == 0) return;
 #ifdef OIGE_LOCO_PRE_NO_RESET  // timing-only build
   return;
 #endif
-  __syncthreads();       // s_list
 
-  // ---- trip 2: reset_idx of the flagged envs on dense lanes (:133-158)
-  const bool mine = tid < cnt;
-  const int64_t kk = (int64_t)k0 + tid;
-  float qv[D];
+  // ---- reset_idx of this wave's dense rows (:133-158)
+  if (a.r.u_pos == nullptr) reset_draws<D>(a.r, di, kk, u);
+  float qp[D], qv[D];
+  reset_dof_rows<D>(a.p, row.dof0, u, qp, qv);
+  const float pot = reset_potential(a.p, row.ip);
   if (mine) {
-    const int64_t i = g * GROUP + s_list[tid];
-    const ResetRow<D> w = reset_load<D>(a.r, i);
-    float u[2 * D], qp[D];
-    reset_draws<D>(a.r, i, kk, u);
-    reset_dof_rows<D>(a.p, w.dof0, u, qp, qv);
-    const float pot = reset_potential(a.p, w.ip);
-    a.b.prev_potentials[i] = pot;
-    a.b.potentials[i] = pot;  // :154
-    a.r.env_ids[kk] = i;
-    *reinterpret_cast<float4*>(a.r.root_rot_out + kk * 4) = w.iq;
+    a.b.prev_potentials[di] = pot;
+    a.b.potentials[di] = pot;  // :154
+    a.r.env_ids[kk] = di;
+    *reinterpret_cast<float4*>(a.r.root_rot_out + kk * 4) = row.iq;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) s_pos3[tid * 3 + c] = w.ip[c];
-    if (STAGE) {
-#pragma unroll
-      for (int j = 0; j < D; ++j) s_rows[tid * D + j] = qp[j];
-    } else {
+    for (int c = 0; c < 3; ++c) a.r.root_pos_out[kk * 3 + c] = row.ip[c];
+    if (!STAGE) {
 #pragma unroll
       for (int c = 0; c < D / 4; ++c) {
         reinterpret_cast<float4*>(a.r.dof_pos_out + kk * D)[c] = make_float4(qp[4 * c], qp[4 * c + 1], qp[4 * c + 2], qp[4 * c + 3]);
@@ -624,26 +640,27 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
       }
     }
   }
-  __syncthreads();
-  // the group's compacted rows are contiguous runs: root_pos (cnt x 3), root_vel (cnt x 6 zeros, :142), the DOF rows
-  {
-    float* dst = a.r.root_pos_out + (int64_t)k0 * 3;
-    for (int e = tid; e < cnt * 3; e += GROUP) dst[e] = s_pos3[e];
-    float2* z = reinterpret_cast<float2*>(a.r.root_vel_out + (int64_t)k0 * 6);  // 24-byte rows: 8-byte aligned
-    for (int e = tid; e < cnt * 3; e += GROUP) z[e] = make_float2(0.f, 0.f);
+  {  // root_vel rows are zeros (:142): the wave's rows are one contiguous run of nw * 6 floats, 8-byte aligned
+    float2* z = reinterpret_cast<float2*>(a.r.root_vel_out + ((int64_t)k0 + row0) * 6);
+    for (int e = lane; e < nw * 3; e += WAVE) z[e] = make_float2(0.f, 0.f);
   }
   if (STAGE) {
-    const int run = cnt * D;
-    float* dst = a.r.dof_pos_out + (int64_t)k0 * D;
-    for (int e = tid; e < run; e += GROUP) dst[e] = s_rows[e];
-    __syncthreads();
-    if (mine) {
+    // Rows that are not whole float4s (Humanoid: 21 floats) would leave each lane walking its own 84-byte row with scalar
+    // stores; the wave's compacted rows are ONE contiguous run of nw * D floats, so they are staged in the wave's own part of
+    // s_rows and written lane-linearly, dof_pos then dof_vel.  Wave-local: no workgroup barrier.
+    float* mine_rows = s_rows + row0 * D;
+    const int run = nw * D;
 #pragma unroll
-      for (int j = 0; j < D; ++j) s_rows[tid * D + j] = qv[j];
-    }
-    __syncthreads();
-    dst = a.r.dof_vel_out + (int64_t)k0 * D;
-    for (int e = tid; e < run; e += GROUP) dst[e] = s_rows[e];
+    for (int j = 0; j < D; ++j) mine_rows[lane * D + j] = qp[j];
+    wave_lds_fence();
+    float* dst = a.r.dof_pos_out + ((int64_t)k0 + row0) * D;
+    for (int e = lane; e < run; e += WAVE) dst[e] = mine_rows[e];
+    wave_lds_fence();
+#pragma unroll
+    for (int j = 0; j < D; ++j) mine_rows[lane * D + j] = qv[j];
+    wave_lds_fence();
+    dst = a.r.dof_vel_out + ((int64_t)k0 + row0) * D;
+    for (int e = lane; e < run; e += WAVE) dst[e] = mine_rows[e];
   }
 }
 
@@ -705,7 +722,12 @@ static int launch_pre(const LocoPre& a, hipStream_t s) {
     if (int rc = launch_count_flags(a.b.reset_buf, a.n, a.b.reset_workspace, s, a.b.tile_counts_u8)) return rc;
   const int rank = pick_rank(G, a.b.tile_counts_u8, LOCO_UNSCANNED_MAX_GROUPS);
   if (rank == RANK_U8) {
+#ifdef OIGE_LOCO_PRE_SPLIT
+    hipLaunchKernelGGL((locomotion_pre_kernel<D, RANK_U8, 1>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+    hipLaunchKernelGGL((locomotion_pre_kernel<D, RANK_U8, 2>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+#else
     hipLaunchKernelGGL((locomotion_pre_kernel<D, RANK_U8>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
+#endif
   } else if (rank == RANK_INT32) {
     hipLaunchKernelGGL((locomotion_pre_kernel<D, RANK_INT32>), dim3((unsigned)G), dim3(GROUP), 0, s, a);
   } else {

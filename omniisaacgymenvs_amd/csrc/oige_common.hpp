@@ -78,6 +78,14 @@ __device__ __forceinline__ int wave_sum(int v) {
 // store, is a wait for that store's round trip to HBM (loads and stores share the counter).
 __device__ __forceinline__ void wait_loads_done() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
+// LDS written by some lanes of this wave is read by others of the SAME wave: the LDS executes a wave's operations in order, so
+// all that is needed is that the compiler keeps them in order and the wave does not run ahead of its own writes.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ int64_t group_rank(bool flagged, const int32_t* group_offsets, int64_t g, int* lds4) {
   const unsigned long long mask = __ballot(flagged);
   const int w = threadIdx.x >> 6;
