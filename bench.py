@@ -896,9 +896,18 @@ def init_rank(dry: bool):
         gpu = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(gpu)
     dev = "cpu" if dry else f"cuda:{gpu}"
-    if world == 1:
+    # OIGE_BENCH_FORCE_GROUP=1: rehearsal of the N>1 code path on ONE GPU with the real backend -- a one-rank RCCL
+    # communicator, so init_process_group(device_id=...), the per-step async all-reduce, Work.wait() on the streams, the
+    # barriers and the MAX reduction of the timing all execute on RCCL (profiles/r03/bench_rccl_one_rank.json)
+    force = os.environ.get("OIGE_BENCH_FORCE_GROUP") == "1"
+    if world == 1 and not force:
         return None, 1, 0, dev, "none"
     import torch.distributed as dist
+
+    if force and world == 1:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
 
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # OIGE_DIST_BACKEND=gloo: rehearsal of the N>1 path on a box with fewer GPUs than ranks (ranks share devices, the
@@ -909,21 +918,6 @@ def init_rank(dry: bool):
     else:
         dist.init_process_group(backend=backend)
     return dist, world, rank, dev, backend
-
-
-def host_warm(task) -> None:
-    """Host-only, between the synchronisation and the start of the clock: build the task's argument blocks a few times (ctypes
-    structs, no launch, nothing on the stream).  The thread comes out of a blocking device synchronisation with the step's
-    Python working set cold -- the first pre_physics_step after it took 100 us on the host against 28 us for the following
-    ones (OIGE_BENCH_DUMP_STEPS=1), 3 % of a 20-step run that no training loop, which never synchronises between steps, pays."""
-    for _ in range(3):
-        for name in ("_params", "_buffers", "_state", "_reset_io"):
-            fn = getattr(task, name, None)
-            if callable(fn):
-                try:
-                    fn()
-                except TypeError:  # a block that needs arguments: leave it
-                    pass
 
 
 def reduce_timing(dist, elapsed: float, dev: str, backend: str) -> dict:
@@ -959,6 +953,8 @@ def main() -> None:
                          "state, about N/1000 resets per step, SURVEY.md a8); default: the r01 workload, 13-25 %% per step")
     ap.add_argument("--event-every", type=int, default=int(os.environ.get("OIGE_BENCH_EVENT_EVERY", "4")),
                     help="HIP-event brackets around pre / post on every k-th timed step (1: every step, as r01 / r02 did)")
+    ap.add_argument("--stats-every", type=int, default=1,
+                    help="N > 1: issue the episode-statistics all-reduce on every k-th step (the device-side fold runs every step)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="PMC-derived HBM bytes per launch of the dominant kernel (profiles/run_profiles.sh) -> roofline.traffic")
     args = ap.parse_args()
@@ -1013,6 +1009,20 @@ def main() -> None:
             bench.task.capture_step(bench.actions)
         bench.pre, bench.post = bench.task.replay_step, (lambda: None)
 
+    # N > 1: the episode-statistics all-reduce runs INSIDE every step (utils/distributed.py: StatsReducer -- device-side fold of
+    # the buffers the post kernel just wrote, one 40-byte all_reduce(async_op=True) on the communicator's stream, consumed one
+    # step late), as a trainer has it (rlgames_utils.py:72-96).  N = 1 has nothing to exchange and runs no fold.
+    reducer = (od.StatsReducer("cpu" if dry else dev, every=args.stats_every, force=os.environ.get("OIGE_BENCH_FORCE_GROUP") == "1")
+               if dist is not None else None)
+    coll_host = [0.0]
+
+    def exchange():
+        if reducer is not None:
+            h = time.perf_counter()
+            tk = bench.task
+            reducer.step(tk.rew_buf, tk.reset_buf, tk.progress_buf, getattr(tk, "successes", None))
+            coll_host[0] += time.perf_counter() - h
+
     def timed_step(es, e0, e1):
         es.record()
         bench.pre()
@@ -1020,6 +1030,7 @@ def main() -> None:
         bench.post()
         e1.record()
         after()
+        exchange()
 
     # the copy calibration (a few dozen streaming copies of the post kernel's footprint) runs first: by the time the W
     # warmup steps start the GPU is at its running clocks, which a 5-step warmup of 0.15 ms steps does not reach by itself
@@ -1034,23 +1045,29 @@ def main() -> None:
         bench.pre()
         bench.post()
         after()
+        exchange()
+    if reducer is not None:  # drain the warm-up's collective; the timed region's statistics start from zero
+        reducer.finish()
+        reducer.acc.zero_()
+        reducer._calls = reducer.collectives = 0
     sync()
     if dist is not None:
         dist.barrier()
     sync()
-    host_warm(bench.task)
+    coll_host[0] = 0.0
     t0 = time.perf_counter()
     if args.graph:  # one graph launch per step, nothing else on the stream; events only around the whole loop
         ev_start[0].record()
         for _ in range(args.steps):
             bench.pre()
+            exchange()
         ev_pairs[-1][1].record()
     else:
         if os.environ.get("OIGE_BENCH_DUMP_STEPS"):  # host-side time of each call of the first steps, to stderr
             host = []
             for es, (e0, e1) in zip(ev_start, ev_pairs):
                 h0 = time.perf_counter(); es.record(); h1 = time.perf_counter(); bench.pre(); h2 = time.perf_counter()
-                e0.record(); bench.post(); h3 = time.perf_counter(); e1.record(); after()
+                e0.record(); bench.post(); h3 = time.perf_counter(); e1.record(); after(); exchange()
                 host.append(tuple(round((b - a) * 1e6, 1) for a, b in ((h0, h1), (h1, h2), (h2, h3))))
             print("host us (record, pre, post):", host[:8], file=sys.stderr)
         else:
@@ -1066,7 +1083,10 @@ def main() -> None:
     # cross-rank exchange, one 40-byte all-reduce over RCCL (utils/distributed.py).  Once per run and not a step of the
     # path, so outside the bracket that times EXACTLY K steps (r01 had it inside: 5 % of a 20-step run).
     t = bench.task
-    job_stats = od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
+    if reducer is not None:  # whole-job means over the K timed steps, from the per-step collectives (drained here, outside the bracket)
+        job_stats = reducer.finish()
+    else:
+        job_stats = od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
 
     timed = []
     if dry:
@@ -1125,6 +1145,11 @@ def main() -> None:
             "rank_ms_per_step": {"min": timing["min"] / args.steps * 1e3, "max": timing["max"] / args.steps * 1e3},
             "collective_backend": {"nccl": "rccl"}.get(backend, backend),
         }
+        if reducer is not None:
+            out["collective"] = {"what": "episode-statistics all_reduce(SUM, async_op=True) of 5 f64 inside the timed step, consumed one step late",
+                                 "bytes": 40, "every": reducer.every, "calls_in_timed_region": reducer.collectives,
+                                 "host_ms_per_step": coll_host[0] / args.steps * 1e3}
+            out["collective_ms_per_step"] = coll_host[0] / args.steps * 1e3
         if graph_ms is not None or graph_note is not None:
             out["graph_ms_per_step"] = graph_ms
             out["graph_value"] = None if graph_ms is None else world * n / (graph_ms * 1e-3)

@@ -1176,6 +1176,30 @@ int oige_observer_accumulate(const oige_observer_batch* batch, double* sums /* (
 int oige_observer_means(double* sums, int64_t* counts, float* means_out /* (num_keys,) */, int32_t num_keys,
                         int32_t clear, oige_stream_t stream);
 
+/* ---- per-step episode statistics of one rank (the multi-GPU path's only exchange) ----------------------------------
+ * The reference runs one process per GPU with its own envs and seed + rank (scripts/rlgames_train.py:114-120,171); what is
+ * combined across ranks is the episode-statistics means the trainer logs (utils/rlgames/rlgames_utils.py:72-96).  This entry
+ * point folds one step of THIS rank's buffers into five running f64 sums on the device,
+ *     acc[0] += sum(rew_buf)   acc[1] += count(reset_buf != 0)   acc[2] += sum(progress_buf where reset_buf != 0)
+ *     acc[3] += sum(successes) (0 when NULL)                    acc[4] += num_envs
+ * in a fixed order (the result does not depend on scheduling); the caller all-reduces `acc` (40 bytes) over RCCL.
+ * Two launches, no allocation, no synchronisation.                                                                     */
+#define OIGE_EPISODE_STATS_MAX_BLOCKS 1024
+
+typedef struct oige_episode_stats_io {
+  const float* rew_buf;        /* (N,) */
+  const void* reset_buf;       /* (N,) int64, or bool / uint8 (AnymalTerrain, anymal_terrain.py:465) */
+  const int64_t* progress_buf; /* (N,) */
+  const float* successes;      /* (N,) or NULL */
+  double* partials;            /* workspace: 4 * oige_episode_stats_blocks(N) doubles, written before it is read */
+  double* acc;                 /* (5,) running sums, read-modify-write */
+  int32_t reset_elem_bytes;    /* 8 or 1 */
+  int32_t reserved0;
+} oige_episode_stats_io;
+
+int64_t oige_episode_stats_blocks(int64_t num_envs);
+int oige_episode_stats_accumulate(const oige_episode_stats_io* io, int64_t num_envs, oige_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

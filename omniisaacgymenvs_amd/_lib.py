@@ -300,6 +300,14 @@ class ObserverBatch(C.Structure):
                 ("reserved0", C.c_int32)]
 
 
+class EpisodeStatsIo(C.Structure):
+    _fields_ = [("rew_buf", _fp), ("reset_buf", _fp), ("progress_buf", _fp), ("successes", _fp), ("partials", _fp), ("acc", _fp),
+                ("reset_elem_bytes", C.c_int32), ("reserved0", C.c_int32)]
+
+
+EPISODE_STATS_MAX_BLOCKS = 1024
+
+
 class CrazyflieParams(C.Structure):
     _fields_ = [("motor_tau_up", _f), ("motor_tau_down", _f), ("prop_max_rot", _f), ("clip_actions", _f), ("thrust_max", _f * 4),
                 ("max_episode_length", C.c_int32), ("reserved0", C.c_int32 * 3)]
@@ -421,6 +429,8 @@ SIGNATURES = {
                                                    C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_uint32, _P]),
     "oige_newhand_cabinet_reset_idx": (C.c_int, [C.POINTER(NewhandCabinetParams), C.POINTER(NewhandCabinetBuffers),
                                                  C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_int64, _P]),
+    "oige_episode_stats_blocks": (C.c_int64, [C.c_int64]),
+    "oige_episode_stats_accumulate": (C.c_int, [C.POINTER(EpisodeStatsIo), C.c_int64, _P]),
     "oige_observer_accumulate": (C.c_int, [C.POINTER(ObserverBatch), _P, _P, _P]),
     "oige_observer_means": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),
@@ -488,7 +498,15 @@ def require_device_tensor(t: torch.Tensor, dtype: torch.dtype, shape, name: str)
         raise OigeError(f"{name}: liboige_hip kernels need a ROCm device tensor, got device {t.device} (no CPU fallback)")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def current_stream(device: torch.device) -> int:
+    """Raw handle of torch's current stream on ``device`` (what the kernels are launched on).  The raw getter costs 0.3 us
+    against 4 us for ``torch.cuda.current_stream(device).cuda_stream`` (two calls per step: a quarter of a 4096-env step)."""
+    if _raw_stream is not None:
+        idx = device.index
+        return _raw_stream(torch.cuda.current_device() if idx is None else idx)
     return torch.cuda.current_stream(device).cuda_stream
 
 

@@ -119,9 +119,25 @@ class SyntheticArticulationView:
         n = int(count.item())  # the host read PhysX would not need; test mode only
         return indices[:n].long()
 
+    def _is_identity(self, indices, rows: int) -> bool:
+        """``indices`` is arange(rows)?  Checked once per index tensor (one host read), remembered by identity + version."""
+        memo = self.__dict__.setdefault("_identity_memo", {})
+        hit = memo.get(id(indices))
+        if hit is not None and hit[0] is indices and hit[1] == indices._version:
+            return hit[2]
+        ok = indices.shape[0] == rows and bool(torch.equal(indices.long(), torch.arange(rows, device=indices.device)))
+        memo[id(indices)] = (indices, indices._version, ok)
+        return ok
+
     def _scatter(self, buf: Tensor, values: Tensor, indices, count) -> None:
-        if values.data_ptr() == buf.data_ptr() and values.shape == buf.shape:
-            return  # the caller edited the view's own buffer in place (clone=False getter, e.g. push_robots): nothing to move
+        if (values.data_ptr() == buf.data_ptr() and values.shape == buf.shape
+                and (indices is None or self._is_identity(indices, buf.shape[0]))):
+            # the caller edited the view's own buffer in place (clone=False getter, e.g. push_robots) and hands it back row for
+            # row: nothing to move, whatever `count` says (a row that "does not land" already holds its own value).  Any other
+            # index list is a real scatter (ADVICE r2)
+            return
+        if values.data_ptr() == buf.data_ptr():
+            values = values.clone()  # a scatter of the buffer onto itself: read everything before the first write
         if count is not None and self.apply_resets == "device":
             # rows k >= count must not land: point them at row 0's target and give them row 0's value (duplicates then write
             # identical data), or -- when count == 0 -- at a row that is rewritten with its own current value

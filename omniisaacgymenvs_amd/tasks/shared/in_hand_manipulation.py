@@ -112,7 +112,18 @@ class InHandManipulationTask(RLTask):
         self.set_up_scene(scene)
 
     # ------------------------------------------------------------------ C-ABI argument blocks
+    _PARAM_SCALARS = ("obs_type", "asymmetric_obs", "max_consecutive_successes", "use_relative_control", "max_episode_length",
+                      "dist_reward_scale", "rot_reward_scale", "rot_eps", "action_penalty_scale", "success_tolerance",
+                      "reach_goal_bonus", "fall_dist", "fall_penalty", "_av_factor_host", "vel_obs_scale", "force_torque_obs_scale",
+                      "hand_dof_speed_scale", "dt", "act_moving_average", "reset_position_noise", "reset_dof_pos_noise",
+                      "reset_dof_vel_noise", "clip_actions")
+
     def _params(self) -> _lib.HandParams:
+        """Cached (RLTask._block): rebuilt when one of the public scalars or the host copy of the tables changed."""
+        d = self.__dict__
+        return self._block("params", (self._host_consts,), [d.get(k) for k in self._PARAM_SCALARS], self._build_params)
+
+    def _build_params(self) -> _lib.HandParams:
         obs_types = _ALLEGRO_OBS_TYPES if self.num_fingertips == 0 else _OBS_TYPES  # AllegroHand has no fingertip bodies
         if self.obs_type not in obs_types:
             raise _lib.OigeError(
@@ -165,6 +176,13 @@ class InHandManipulationTask(RLTask):
         }
 
     def _buffers(self) -> _lib.HandBuffers:
+        ts = (self.obs_buf, self.states_buf if self._num_states > 0 else None, self.rew_buf, self.reset_buf, self.reset_goal_buf,
+              self.progress_buf, self.successes, self.consecutive_successes, self.goal_pos, self.goal_rot, self.actions,
+              self.prev_targets, self.cur_targets, self.randomization_buf if self._dr_randomizer.randomize else None,
+              self._reset_workspace, self._goal_workspace, self._reduce_workspace)
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.HandBuffers:
         n = self._num_envs
         rq = _lib.require_device_tensor
         rq(self.obs_buf, torch.float32, (n, self._num_observations), "obs_buf")
@@ -198,11 +216,23 @@ class InHandManipulationTask(RLTask):
 
     def _state(self) -> _lib.HandState:
         """The view getters of get_object_goal_observations (:256-261) and shadow_hand.py:123-135."""
-        n, nf, nd = self._num_envs, self.num_fingertips, self.num_hand_dofs
+        nf = self.num_fingertips
         object_pos, object_rot = self._objects.get_world_poses(clone=False)
         object_velocities = self._objects.get_velocities(clone=False)
         hand_dof_pos = self._hands.get_joint_positions(clone=False)
         hand_dof_vel = self._hands.get_joint_velocities(clone=False)
+        fingers = sensors = (None,)
+        if nf > 0:  # shadow_hand.py:123-127
+            fingers = (*self._hands._fingers.get_world_poses(clone=False), self._hands._fingers.get_velocities(clone=False))
+        want_sensor = self.obs_type == "full_state" or self.asymmetric_obs
+        if want_sensor:
+            sensors = (self._hands.get_measured_joint_forces(joint_indices=self._hands._sensor_indices),)
+        live = (object_pos, object_rot, object_velocities, hand_dof_pos, hand_dof_vel, self._env_pos, *fingers, *sensors)
+        return self._block("state", live, (nf, want_sensor), lambda: self._build_state(live, nf, want_sensor))
+
+    def _build_state(self, live, nf, want_sensor) -> _lib.HandState:
+        n, nd = self._num_envs, self.num_hand_dofs
+        object_pos, object_rot, object_velocities, hand_dof_pos, hand_dof_vel = live[:5]
         rq = _lib.require_device_tensor
         rq(object_pos, torch.float32, (n, 3), "object_pos")
         rq(object_rot, torch.float32, (n, 4), "object_rot")
@@ -213,23 +243,18 @@ class InHandManipulationTask(RLTask):
         s = _lib.HandState()
         s.object_pos, s.object_rot, s.object_velocities = object_pos.data_ptr(), object_rot.data_ptr(), object_velocities.data_ptr()
         s.hand_dof_pos, s.hand_dof_vel = hand_dof_pos.data_ptr(), hand_dof_vel.data_ptr()
-        keep = [object_pos, object_rot, object_velocities, hand_dof_pos, hand_dof_vel]
         if nf > 0:  # shadow_hand.py:123-127
-            fingertip_pos, fingertip_rot = self._hands._fingers.get_world_poses(clone=False)
-            fingertip_velocities = self._hands._fingers.get_velocities(clone=False)
+            fingertip_pos, fingertip_rot, fingertip_velocities = live[6:9]
             rq(fingertip_pos, torch.float32, (n * nf, 3), "fingertip_pos")
             rq(fingertip_rot, torch.float32, (n * nf, 4), "fingertip_rot")
             rq(fingertip_velocities, torch.float32, (n * nf, 6), "fingertip_velocities")
             s.fingertip_pos, s.fingertip_rot = fingertip_pos.data_ptr(), fingertip_rot.data_ptr()
             s.fingertip_velocities = fingertip_velocities.data_ptr()
-            keep += [fingertip_pos, fingertip_rot, fingertip_velocities]
-        if self.obs_type == "full_state" or self.asymmetric_obs:
-            vec_sensor = self._hands.get_measured_joint_forces(joint_indices=self._hands._sensor_indices)
+        if want_sensor:
+            vec_sensor = live[-1]
             rq(vec_sensor, torch.float32, (n, nf, 6), "vec_sensor_tensor")
             s.vec_sensor = vec_sensor.data_ptr()
-            keep.append(vec_sensor)
         s.env_pos = self._env_pos.data_ptr()
-        self._live_state = keep
         return s
 
     def _post(self, stages: int, obs_noise=None) -> None:
@@ -294,6 +319,13 @@ class InHandManipulationTask(RLTask):
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def _reset_io(self, u_goal=None, u_reset=None, u_reset_goal=None) -> _lib.HandResetIO:
+        ts = (self.object_init_pos, self.goal_init_pos, self._env_pos, u_goal, u_reset, u_reset_goal, *self._reset_out.values(),
+              self._step_dev if self._capturing else None)
+        r = self._block("reset_io", ts, (self._rand_seed,), lambda: self._build_reset_io(u_goal, u_reset, u_reset_goal))
+        r.step = self._step_count  # the one field that changes from step to step
+        return r
+
+    def _build_reset_io(self, u_goal, u_reset, u_reset_goal) -> _lib.HandResetIO:
         r = _lib.HandResetIO()
         r.object_init_pos, r.goal_init_pos = self.object_init_pos.data_ptr(), self.goal_init_pos.data_ptr()
         r.env_pos = self._env_pos.data_ptr()
@@ -323,10 +355,16 @@ class InHandManipulationTask(RLTask):
 
     def _apply_reset_writes(self, n=None) -> None:
         o = self._reset_out
-        if n is None:
-            kw, sl = dict(indices=o["env_ids"], count=o["count"]), slice(None)
-        else:
-            kw, sl = dict(indices=o["env_ids"][:n].to(torch.int32)), slice(0, n)
+        if n is None:  # whole-capacity buffers + the device-side count: nothing to slice
+            ids, cnt = o["env_ids"], o["count"]
+            self._goals.set_world_poses(o["r_goal_world_pos"], o["r_goal_rot"], indices=ids, count=cnt)
+            self._objects.set_velocities(o["object_vel"], indices=ids, count=cnt)
+            self._objects.set_world_poses(o["object_pos"], o["object_rot"], indices=ids, count=cnt)
+            self._hands.set_joint_position_targets(o["dof_pos"], indices=ids, count=cnt)
+            self._hands.set_joint_positions(o["dof_pos"], indices=ids, count=cnt)
+            self._hands.set_joint_velocities(o["dof_vel"], indices=ids, count=cnt)
+            return
+        kw, sl = dict(indices=o["env_ids"][:n].to(torch.int32)), slice(0, n)
         self._goals.set_world_poses(o["r_goal_world_pos"][sl], o["r_goal_rot"][sl], **kw)
         self._objects.set_velocities(o["object_vel"][sl], **kw)
         self._objects.set_world_poses(o["object_pos"][sl], o["object_rot"][sl], **kw)
@@ -342,8 +380,7 @@ class InHandManipulationTask(RLTask):
         if action_noise is not None and not self.sync_free:
             raise _lib.OigeError("pre_physics_step(action_noise=...) needs task.sync_free")
         n = self._num_envs
-        actions = actions.to(self.device)
-        _lib.require_device_tensor(actions, torch.float32, (n, self._num_actions), "actions")
+        actions = self._block("actions_in", (actions,), (), lambda: self._checked_actions(actions))
         self._advance_step_counter()
         flags = 0
         o = self._reset_out
@@ -378,6 +415,11 @@ class InHandManipulationTask(RLTask):
             self._apply_goal_writes(None)
             self._apply_reset_writes(None)
         self._hands.set_joint_position_targets(self._targets_out, indices=None, joint_indices=self.actuated_dof_indices)
+
+    def _checked_actions(self, actions):
+        actions = actions.to(self.device)
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, self._num_actions), "actions")
+        return actions
 
     def reset_target_pose(self, env_ids):
         n = len(env_ids)

@@ -69,8 +69,16 @@ class LocomotionTask(RLTask):
         pass
 
     # ------------------------------------------------------------------ C-ABI argument blocks
+    _PARAM_SCALARS = ("dt", "dof_vel_scale", "contact_force_scale", "angular_velocity_scale", "heading_weight", "up_weight",
+                      "actions_cost_scale", "energy_cost_scale", "joints_at_limit_cost_scale", "death_cost", "termination_height",
+                      "alive_reward_scale", "_max_episode_length", "power_scale", "clip_actions")
+
     def _params(self) -> _lib.LocomotionParams:
-        """Rebuilt on demand so edits to the public scalars (e.g. ``task.heading_weight``) take effect."""
+        """Rebuilt when a public scalar (e.g. ``task.heading_weight``) or the host copy of the constant tables changed."""
+        d = self.__dict__
+        return self._block("params", (self._host_consts,), [d[k] for k in self._PARAM_SCALARS], self._build_params)
+
+    def _build_params(self) -> _lib.LocomotionParams:
         p = _lib.LocomotionParams()
         d = self._robots.num_dof
         p.num_dof, p.num_sensors, p.limit_cost_kind = d, self._num_sensors, self._limit_cost_kind
@@ -102,7 +110,7 @@ class LocomotionTask(RLTask):
         return p
 
     def _refresh_host_consts(self) -> None:
-        """Row 0 of the per-env-constant tensors + the (D,) tables, read to the host once."""
+        """Row 0 of the per-env-constant tensors + the (D,) tables, read to the host once (a NEW dict: the params block's key)."""
         self._host_consts = {
             "target": self.targets[0].tolist(),
             "inv_start_rot": self.inv_start_rot[0].tolist(),
@@ -115,6 +123,12 @@ class LocomotionTask(RLTask):
         }
 
     def _buffers(self) -> _lib.LocomotionBuffers:
+        vecs = self.materialize_vecs
+        ts = (self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf, self.potentials, self.prev_potentials, self.actions,
+              self.up_vec if vecs else None, self.heading_vec if vecs else None, self._reset_workspace, self._tile_counts_u8)
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.LocomotionBuffers:
         n, d = self._num_envs, self._robots.num_dof
         rq = _lib.require_device_tensor
         rq(self.obs_buf, torch.float32, (n, self._num_observations), "obs_buf")
@@ -138,13 +152,17 @@ class LocomotionTask(RLTask):
         return b
 
     def _state(self) -> _lib.LocomotionState:
-        n, d = self._num_envs, self._robots.num_dof
         torso_position, torso_rotation = self._robots.get_world_poses(clone=False)
         velocities = self._robots.get_velocities(clone=False)
         dof_pos = self._robots.get_joint_positions(clone=False)
         dof_vel = self._robots.get_joint_velocities(clone=False)
         # force sensors attached to the feet
         sensor_force_torques = self._robots.get_measured_joint_forces(joint_indices=self._sensor_indices)
+        live = (torso_position, torso_rotation, velocities, dof_pos, dof_vel, sensor_force_torques)
+        return self._block("state", live, (), lambda: self._build_state(*live))
+
+    def _build_state(self, torso_position, torso_rotation, velocities, dof_pos, dof_vel, sensor_force_torques) -> _lib.LocomotionState:
+        n, d = self._num_envs, self._robots.num_dof
         rq = _lib.require_device_tensor
         rq(torso_position, torch.float32, (n, 3), "torso_position")
         rq(torso_rotation, torch.float32, (n, 4), "torso_rotation")
@@ -157,7 +175,6 @@ class LocomotionTask(RLTask):
         s.velocities = velocities.data_ptr()
         s.dof_pos, s.dof_vel = dof_pos.data_ptr(), dof_vel.data_ptr()
         s.sensor_force_torques = sensor_force_torques.data_ptr()
-        self._live_state = (torso_position, torso_rotation, velocities, dof_pos, dof_vel, sensor_force_torques)
         return s
 
     def _post(self, stages: int) -> None:
@@ -205,6 +222,14 @@ class LocomotionTask(RLTask):
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def _reset_io(self, u_pos=None, u_vel=None) -> _lib.LocomotionResetIO:
+        o = self._reset_out
+        ts = (self.initial_root_pos, self.initial_root_rot, self.initial_dof_pos, u_pos, u_vel, o["env_ids"], o["count"], o["dof_pos"],
+              o["dof_vel"], o["root_pos"], o["root_rot"], o["root_vel"], self._step_dev if self._capturing else None)
+        r = self._block("reset_io", ts, (self._rand_seed,), lambda: self._build_reset_io(u_pos, u_vel))
+        r.step = self._step_count  # the one field that changes from step to step
+        return r
+
+    def _build_reset_io(self, u_pos, u_vel) -> _lib.LocomotionResetIO:
         r = _lib.LocomotionResetIO()
         r.initial_root_pos = self.initial_root_pos.data_ptr()
         r.initial_root_rot = self.initial_root_rot.data_ptr()
@@ -212,7 +237,6 @@ class LocomotionTask(RLTask):
         if u_pos is not None:
             r.u_pos, r.u_vel = u_pos.data_ptr(), u_vel.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
-        r.step = self._step_count
         r.step_ptr = self._graph_step_ptr()  # graph capture: the Philox step counter lives on the device
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
@@ -224,12 +248,15 @@ class LocomotionTask(RLTask):
     def _apply_reset_writes(self, n=None) -> None:
         """Hand the compacted rows to the view setters (:145-149).  ``n`` None -> device count."""
         o = self._reset_out
-        if n is None:
-            kw = dict(indices=o["env_ids"], count=o["count"])
-            sl = slice(None)
-        else:
-            kw = dict(indices=o["env_ids"][:n])
-            sl = slice(0, n)
+        if n is None:  # whole-capacity buffers + the device-side count: nothing to slice
+            ids, cnt, r = o["env_ids"], o["count"], self._robots
+            r.set_joint_positions(o["dof_pos"], indices=ids, count=cnt)
+            r.set_joint_velocities(o["dof_vel"], indices=ids, count=cnt)
+            r.set_world_poses(o["root_pos"], o["root_rot"], indices=ids, count=cnt)
+            r.set_velocities(o["root_vel"], indices=ids, count=cnt)
+            return
+        kw = dict(indices=o["env_ids"][:n])
+        sl = slice(0, n)
         self._robots.set_joint_positions(o["dof_pos"][sl], **kw)
         self._robots.set_joint_velocities(o["dof_vel"][sl], **kw)
         self._robots.set_world_poses(o["root_pos"][sl], o["root_rot"][sl], **kw)
@@ -238,9 +265,8 @@ class LocomotionTask(RLTask):
     def pre_physics_step(self, actions) -> None:
         if not self.world.is_playing():
             return
-        n, d = self._num_envs, self._robots.num_dof
-        actions = actions.to(self._device)
-        _lib.require_device_tensor(actions, torch.float32, (n, d), "actions")
+        n = self._num_envs
+        actions = self._block("actions_in", (actions,), (), lambda: self._checked_actions(actions))
         self._advance_step_counter()
         flags = 0
         if not self.sync_free:
@@ -265,6 +291,11 @@ class LocomotionTask(RLTask):
             self._apply_reset_writes(None)
         # applies joint torques
         self._robots.set_joint_efforts(self._forces, indices=self._all_indices)
+
+    def _checked_actions(self, actions):
+        actions = actions.to(self._device)
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, self._robots.num_dof), "actions")
+        return actions
 
     def reset_idx(self, env_ids):
         num_resets = len(env_ids)

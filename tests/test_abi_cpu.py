@@ -83,7 +83,8 @@ def test_every_entry_point_rejects_null_arguments_without_touching_the_gpu():
     """All-NULL / zero arguments: every compute entry point must come back with a negative code and a message (never a
     crash, never a launch).  Validation runs before any HIP call, so this is safe without a device."""
     lib = _lib.load()
-    pure = {"oige_version", "oige_num_tiles", "oige_workspace_ints", "oige_tile_counts_u8_bytes", "oige_last_error", "oige_compact_static_max_envs"}
+    pure = {"oige_version", "oige_num_tiles", "oige_workspace_ints", "oige_tile_counts_u8_bytes", "oige_last_error", "oige_compact_static_max_envs",
+            "oige_episode_stats_blocks"}
     checked = 0
     for name, (res, args) in _lib.SIGNATURES.items():
         if name in pure:

@@ -25,7 +25,11 @@ def test_gpus_2_launches_two_ranks():
     out, err = _run(["--gpus", "2", "--envs", "1000"])
     assert "torch.distributed.run" in err  # the parent was the launcher
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["collective_backend"] == "gloo"
-    assert out["config"]["episode_stats"]["num_envs"] == 2000  # both ranks' envs reached the all-reduce
+    st = out["config"]["episode_stats"]
+    assert st["num_envs"] == 2000 and st["env_steps"] == 2000 * 4 and st["steps"] == 4  # both ranks' envs reached the all-reduce, every step
+    # the collective sits INSIDE the timed step: one per step, and its host cost is on the line
+    assert out["collective"]["calls_in_timed_region"] == 4 and out["collective"]["every"] == 1 and out["collective"]["bytes"] == 40
+    assert out["collective_ms_per_step"] > 0
     assert out["rank_ms_per_step"]["min"] <= out["rank_ms_per_step"]["max"] == out["ms_per_step"]
     assert abs(out["value"] - 2 * 1000 * 4 / (out["ms_per_step"] * 4e-3)) < 1e-6 * out["value"]
     assert out["scaling"] == "weak" and out["data"] == "dry-run"
@@ -40,6 +44,13 @@ def test_single_rank_needs_no_launcher():
     out, err = _run(["--envs", "256"])
     assert "torch.distributed.run" not in err
     assert out["n_gpus"] == 1 and out["ranks_seen"] == 1 and out["collective_backend"] == "none"
+    assert "collective" not in out  # nothing to exchange at N = 1: no fold, no collective
+
+
+def test_stats_every_k_steps():
+    out, _ = _run(["--gpus", "2", "--envs", "512", "--stats-every", "2"])
+    assert out["collective"]["calls_in_timed_region"] == 2 and out["collective"]["every"] == 2
+    assert out["config"]["episode_stats"]["env_steps"] == 2 * 512 * 4
 
 
 def test_bench_does_not_import_the_oracle_or_tests_at_module_scope():
