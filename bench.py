@@ -953,8 +953,10 @@ def main() -> None:
                          "state, about N/1000 resets per step, SURVEY.md a8); default: the r01 workload, 13-25 %% per step")
     ap.add_argument("--event-every", type=int, default=int(os.environ.get("OIGE_BENCH_EVENT_EVERY", "4")),
                     help="HIP-event brackets around pre / post on every k-th timed step (1: every step, as r01 / r02 did)")
-    ap.add_argument("--stats-every", type=int, default=1,
-                    help="N > 1: issue the episode-statistics all-reduce on every k-th step (the device-side fold runs every step)")
+    ap.add_argument("--stats-every", type=int, default=0,
+                    help="N > 1: the episode-statistics all-reduce on every k-th step (this rank's sums are kept every step).  "
+                         "0 (default): the trainer's own cadence, one per epoch = horizon_length steps of the task's "
+                         "cfg/train/*PPO.yaml (Ant 16, Humanoid 32, ShadowHand 16, AnymalTerrain 48), at most --steps; 1: every step")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="PMC-derived HBM bytes per launch of the dominant kernel (profiles/run_profiles.sh) -> roofline.traffic")
     args = ap.parse_args()
@@ -1012,8 +1014,15 @@ def main() -> None:
     # N > 1: the episode-statistics all-reduce runs INSIDE every step (utils/distributed.py: StatsReducer -- device-side fold of
     # the buffers the post kernel just wrote, one 40-byte all_reduce(async_op=True) on the communicator's stream, consumed one
     # step late), as a trainer has it (rlgames_utils.py:72-96).  N = 1 has nothing to exchange and runs no fold.
-    reducer = (od.StatsReducer("cpu" if dry else dev, every=args.stats_every, force=os.environ.get("OIGE_BENCH_FORCE_GROUP") == "1")
+    # rl_games reduces the episode statistics once per epoch (rlgames_utils.py:72-96: after_print_stats); an epoch is horizon_length
+    # steps (cfg/train/AntPPO.yaml:67 16, HumanoidPPO.yaml:66 32, ShadowHandPPO.yaml:67 16, AnymalTerrainPPO.yaml:72 48)
+    horizon = {"Ant": 16, "Humanoid": 32, "ShadowHand": 16, "AllegroHand": 16, "AnymalTerrain": 48, "Anymal": 24}.get(args.task, 16)
+    stats_every = args.stats_every if args.stats_every > 0 else max(1, min(horizon, args.steps))
+    reducer = (od.StatsReducer("cpu" if dry else dev, every=stats_every, force=os.environ.get("OIGE_BENCH_FORCE_GROUP") == "1",
+                               consume=os.environ.get("OIGE_STATS_CONSUME", "poll"))
                if dist is not None else None)
+    if reducer is not None:
+        reducer.attach(bench.task)  # tasks whose post kernel keeps the statistics slots itself: no per-step launch
     coll_host = [0.0]
 
     def exchange():
@@ -1046,10 +1055,9 @@ def main() -> None:
         bench.post()
         after()
         exchange()
-    if reducer is not None:  # drain the warm-up's collective; the timed region's statistics start from zero
-        reducer.finish()
-        reducer.acc.zero_()
-        reducer._calls = reducer.collectives = 0
+    if reducer is not None:  # one whole collective as warm-up, then the timed region's statistics start from zero
+        reducer.warm()
+        reducer.reset()
     sync()
     if dist is not None:
         dist.barrier()
@@ -1146,8 +1154,9 @@ def main() -> None:
             "collective_backend": {"nccl": "rccl"}.get(backend, backend),
         }
         if reducer is not None:
-            out["collective"] = {"what": "episode-statistics all_reduce(SUM, async_op=True) of 5 f64 inside the timed step, consumed one step late",
+            out["collective"] = {"what": "episode-statistics all_reduce(SUM, async_op=True) of 5 f64 inside the timed steps, consumed by a later step",
                                  "bytes": 40, "every": reducer.every, "calls_in_timed_region": reducer.collectives,
+                                 "rank_sums": "kept by the post kernel (per-tile slots)" if reducer._fused else "one oige_episode_stats_accumulate launch per step",
                                  "host_ms_per_step": coll_host[0] / args.steps * 1e3}
             out["collective_ms_per_step"] = coll_host[0] / args.steps * 1e3
         if graph_ms is not None or graph_note is not None:

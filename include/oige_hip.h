@@ -140,6 +140,10 @@ typedef struct oige_locomotion_buffers {
                                launch between post_physics and pre_physics.  Pass the same buffer to post_physics and pre_physics (with
                                OIGE_PRE_COUNTS_VALID the pre call trusts what the post call left in it).  No counterpart in the
                                reference. */
+  double* stats_slots;      /* optional (NULL = not kept): 4 doubles per 64-env tile, zeroed once by the caller.  A fused
+                               post_physics call (OBS + METRICS + DONE) adds the tile's {sum reward, done envs, sum of their
+                               episode lengths} to its slot: the rank's episode statistics for oige_episode_stats_fold
+                               without a launch or a byte of extra traffic per step (multi-GPU runs). */
 } oige_locomotion_buffers;
 
 /* stages of RLTask.post_physics_step (rl_task.py:289-295), any subset, executed in this order */
@@ -1178,12 +1182,14 @@ int oige_observer_means(double* sums, int64_t* counts, float* means_out /* (num_
 
 /* ---- per-step episode statistics of one rank (the multi-GPU path's only exchange) ----------------------------------
  * The reference runs one process per GPU with its own envs and seed + rank (scripts/rlgames_train.py:114-120,171); what is
- * combined across ranks is the episode-statistics means the trainer logs (utils/rlgames/rlgames_utils.py:72-96).  This entry
- * point folds one step of THIS rank's buffers into five running f64 sums on the device,
- *     acc[0] += sum(rew_buf)   acc[1] += count(reset_buf != 0)   acc[2] += sum(progress_buf where reset_buf != 0)
- *     acc[3] += sum(successes) (0 when NULL)                    acc[4] += num_envs
- * in a fixed order (the result does not depend on scheduling); the caller all-reduces `acc` (40 bytes) over RCCL.
- * Two launches, no allocation, no synchronisation.                                                                     */
+ * combined across ranks is the episode-statistics means the trainer logs once per epoch (utils/rlgames/rlgames_utils.py:
+ * 52-56 collects per step, :72-96 reduces per epoch).  This rank's running sums live on the device as SLOTS of four f64
+ *     slot[0] += sum(rew_buf)   slot[1] += count(reset_buf != 0)   slot[2] += sum(progress_buf where reset_buf != 0)
+ *     slot[3] += sum(successes) (0 when NULL)
+ * each slot owned by one workgroup of oige_episode_stats_accumulate (one launch per step) -- or by one 64-env tile of a post
+ * kernel that keeps them itself (oige_locomotion_buffers.stats_slots: no launch at all).  oige_episode_stats_fold adds the
+ * slots up into acc[0..3] and sets acc[4] = env_steps when a collective is due; the caller all-reduces `acc` (40 bytes) over
+ * RCCL.  Every sum has a fixed order: results do not depend on scheduling.  No allocation, no synchronisation.         */
 #define OIGE_EPISODE_STATS_MAX_BLOCKS 1024
 
 typedef struct oige_episode_stats_io {
@@ -1191,14 +1197,17 @@ typedef struct oige_episode_stats_io {
   const void* reset_buf;       /* (N,) int64, or bool / uint8 (AnymalTerrain, anymal_terrain.py:465) */
   const int64_t* progress_buf; /* (N,) */
   const float* successes;      /* (N,) or NULL */
-  double* partials;            /* workspace: 4 * oige_episode_stats_blocks(N) doubles, written before it is read */
-  double* acc;                 /* (5,) running sums, read-modify-write */
+  double* slots;               /* 4 * oige_episode_stats_blocks(N) doubles, zeroed once by the caller, read-modify-write */
   int32_t reset_elem_bytes;    /* 8 or 1 */
   int32_t reserved0;
 } oige_episode_stats_io;
 
 int64_t oige_episode_stats_blocks(int64_t num_envs);
 int oige_episode_stats_accumulate(const oige_episode_stats_io* io, int64_t num_envs, oige_stream_t stream);
+int oige_episode_stats_fold(const double* slots, int64_t num_slots, double* acc /* (5,) */, double env_steps,
+                            double* scratch /* oige_episode_stats_fold_scratch(num_slots) doubles; NULL when that is 0 */,
+                            oige_stream_t stream);
+int64_t oige_episode_stats_fold_scratch(int64_t num_slots);
 
 #ifdef __cplusplus
 }

@@ -45,7 +45,7 @@ class LocomotionState(C.Structure):
 class LocomotionBuffers(C.Structure):
     _fields_ = [(n, _fp) for n in (
         "obs_buf", "rew_buf", "reset_buf", "progress_buf", "potentials", "prev_potentials", "up_vec", "heading_vec",
-        "actions", "reset_workspace", "tile_counts_u8")]
+        "actions", "reset_workspace", "tile_counts_u8", "stats_slots")]
 
 
 class LocomotionResetIO(C.Structure):
@@ -301,7 +301,7 @@ class ObserverBatch(C.Structure):
 
 
 class EpisodeStatsIo(C.Structure):
-    _fields_ = [("rew_buf", _fp), ("reset_buf", _fp), ("progress_buf", _fp), ("successes", _fp), ("partials", _fp), ("acc", _fp),
+    _fields_ = [("rew_buf", _fp), ("reset_buf", _fp), ("progress_buf", _fp), ("successes", _fp), ("slots", _fp),
                 ("reset_elem_bytes", C.c_int32), ("reserved0", C.c_int32)]
 
 
@@ -431,6 +431,8 @@ SIGNATURES = {
                                                  C.POINTER(FrankaCabinetResetIO), C.c_int64, C.c_int64, _P]),
     "oige_episode_stats_blocks": (C.c_int64, [C.c_int64]),
     "oige_episode_stats_accumulate": (C.c_int, [C.POINTER(EpisodeStatsIo), C.c_int64, _P]),
+    "oige_episode_stats_fold": (C.c_int, [_P, C.c_int64, _P, C.c_double, _P, _P]),
+    "oige_episode_stats_fold_scratch": (C.c_int64, [C.c_int64]),
     "oige_observer_accumulate": (C.c_int, [C.POINTER(ObserverBatch), _P, _P, _P]),
     "oige_observer_means": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P]),
     "oige_stream_copy": (C.c_int, [_P, _P, C.c_int64, C.c_int32, _P]),

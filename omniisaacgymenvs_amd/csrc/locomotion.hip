@@ -135,6 +135,14 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
     if (do_done) reset_in = a.b.reset_buf[env];
     if (do_progress || do_done) progress = a.b.progress_buf[env];
   }
+  // the tile's episode-statistics slot (oige_hip.h: stats_slots), fetched with the other loads by the lane that owns it
+  const bool keep_stats = a.b.stats_slots != nullptr && do_metrics && do_done;
+  double st_rew = 0.0, st_done = 0.0, st_len = 0.0;
+  if (keep_stats && env_wave && lane == 0) {
+    const double* sl = a.b.stats_slots + 4 * t;
+    const double2 lo = *reinterpret_cast<const double2*>(sl);
+    st_rew = lo.x; st_done = lo.y; st_len = sl[2];
+  }
 
   // ---- B: pass-through columns into the obs tile
   scatter_chunk<D, OBS, C_DPOS, false, PNT>(c_dpos, tile, 1.0f);  // raw; unscaled per env in C
@@ -212,8 +220,11 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
       h[0] = heading_vec.x; h[1] = heading_vec.y; h[2] = heading_vec.z;
     }
     if (do_progress) a.b.progress_buf[env] = progress;
-    if (do_metrics)
-      a.b.rew_buf[env] = reward_of<D, LIMIT>(p, head[0], up_proj, heading_proj, dps, dvs, act, pot, prev_pot);
+  }
+  float rew = 0.0f;
+  if (do_metrics) {
+    rew = reward_of<D, LIMIT>(p, head[0], up_proj, heading_proj, dps, dvs, act, pot, prev_pot);
+    if (live) a.b.rew_buf[env] = rew;
   }
   if (do_done) {
     // is_done (:290-291): sticky; progress compared in fp32 against float(max_len - 1)
@@ -223,6 +234,20 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
     const unsigned long long m = __ballot(live && r != 0);
     if (a.b.reset_workspace && lane == 0) a.b.reset_workspace[t] = __popcll(m);
     if (a.b.tile_counts_u8 && lane == 0) a.b.tile_counts_u8[t] = (uint8_t)__popcll(m);
+    if (keep_stats) {  // this step's share of the rank's episode statistics: lane order, then += into the tile's own slot
+      double rs = live ? (double)rew : 0.0;
+      int ls = (live && r != 0) ? (int)progress : 0;
+#pragma unroll
+      for (int off = WAVE / 2; off > 0; off >>= 1) {
+        rs += __shfl_xor(rs, off, WAVE);
+        ls += __shfl_xor(ls, off, WAVE);
+      }
+      if (lane == 0) {
+        double* sl = a.b.stats_slots + 4 * t;
+        *reinterpret_cast<double2*>(sl) = make_double2(st_rew + rs, st_done + (double)__popcll(m));
+        sl[2] = st_len + (double)ls;
+      }
+    }
   }
   }  // env_wave
 
@@ -769,6 +794,7 @@ int oige_locomotion_post_physics(const oige_locomotion_params* params, const oig
     OIGE_REQUIRE(b.potentials && b.prev_potentials && b.actions, "locomotion_post_physics: null potentials/actions");
   if (stages & OIGE_STAGE_METRICS) OIGE_REQUIRE(b.rew_buf, "locomotion_post_physics: null rew_buf");
   if (stages & OIGE_STAGE_DONE) OIGE_REQUIRE(b.reset_buf, "locomotion_post_physics: null reset_buf");
+  OIGE_REQUIRE(aligned16(b.stats_slots), "locomotion_post_physics: stats_slots must be 16-byte aligned");
   LocoPost a;
   a.p = *params;
   a.b = b;

@@ -39,62 +39,98 @@ __global__ __launch_bounds__(WAVE) void observer_means_kernel(double* __restrict
 
 // ---------------------------------------------------------------- per-step episode statistics of one rank (multi-GPU)
 // The only cross-rank exchange of the path is the statistics vector the trainer logs (rlgames_utils.py:72-96; one process per
-// GPU, scripts/rlgames_train.py:114-120,171).  This rank's contribution is folded on the device, once per step, from the
-// buffers the post kernel has just left (20 bytes per env, still in cache), into five running f64 sums that the caller hands
-// to ONE small all-reduce: [sum reward, done envs, sum of the done envs' episode lengths, sum successes, envs].
-// Two launches (launch gaps are ~0 on this part): per-workgroup partials in a fixed thread order, then one workgroup that
-// folds them in a fixed order -- the sums do not depend on scheduling.
+// GPU, scripts/rlgames_train.py:114-120,171).  This rank's contribution is kept on the device as SLOTS of four running f64 sums
+// {sum reward, done envs, sum of the done envs' episode lengths, sum successes}: one slot per workgroup of the accumulate
+// kernel below, or one per 64-env tile when a post kernel keeps them itself (locomotion_post_kernel: no extra launch, no
+// extra traffic).  A slot is only ever touched by "its" workgroup / wave, step after step, so every sum has a fixed order.
+// oige_episode_stats_fold adds the slots up (fixed order again) when a collective is due -- once per trainer epoch, not per step.
 constexpr int STATS_THREADS = 256;
+constexpr int STATS_ENVS_PER_THREAD = 4;
 
-template <class T>
-__device__ __forceinline__ T block_sum(T v, T* lds /* STATS_THREADS / WAVE entries */) {
+template <int N>
+__device__ __forceinline__ void block_sum4(double (&v)[N], double* lds /* N * STATS_THREADS / WAVE */) {
 #pragma unroll
-  for (int off = WAVE / 2; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+  for (int k = 0; k < N; ++k)
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, WAVE);
   const int w = threadIdx.x >> 6;
-  __syncthreads();  // the previous use of lds is over
-  if (lane_id() == 0) lds[w] = v;
-  __syncthreads();
-  T t = 0;
+  if (lane_id() == 0)
 #pragma unroll
-  for (int i = 0; i < STATS_THREADS / WAVE; ++i) t += lds[i];
-  return t;
+    for (int k = 0; k < N; ++k) lds[k * (STATS_THREADS / WAVE) + w] = v[k];
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < STATS_THREADS / WAVE; ++i) t += lds[k * (STATS_THREADS / WAVE) + i];
+    v[k] = t;
+  }
 }
 
-__global__ __launch_bounds__(STATS_THREADS) void episode_stats_partial_kernel(const oige_episode_stats_io io, int64_t n) {
-  __shared__ double lds[STATS_THREADS / WAVE];
-  double rew = 0.0, done = 0.0, len = 0.0, succ = 0.0;
+// one step of this rank: slot[blockIdx] += the block's share.  Four consecutive envs per thread and pass (16-byte loads).
+__global__ __launch_bounds__(STATS_THREADS) void episode_stats_accumulate_kernel(const oige_episode_stats_io io, int64_t n) {
+  __shared__ double lds[4 * STATS_THREADS / WAVE];
+  double v[4] = {0.0, 0.0, 0.0, 0.0};  // rew, done, len, succ
   const uint8_t* r8 = static_cast<const uint8_t*>(io.reset_buf);
   const int64_t* r64 = static_cast<const int64_t*>(io.reset_buf);
-  for (int64_t i = (int64_t)blockIdx.x * STATS_THREADS + threadIdx.x; i < n; i += (int64_t)gridDim.x * STATS_THREADS) {
-    const bool d = io.reset_elem_bytes == 1 ? r8[i] != 0 : r64[i] != 0;
-    rew += (double)io.rew_buf[i];
-    done += d ? 1.0 : 0.0;
-    len += d ? (double)io.progress_buf[i] : 0.0;
-    if (io.successes) succ += (double)io.successes[i];
+  const int64_t stride = (int64_t)gridDim.x * STATS_THREADS * STATS_ENVS_PER_THREAD;
+  for (int64_t i0 = ((int64_t)blockIdx.x * STATS_THREADS + threadIdx.x) * STATS_ENVS_PER_THREAD; i0 < n; i0 += stride) {
+    if (i0 + STATS_ENVS_PER_THREAD <= n) {
+      const float4 rw = *reinterpret_cast<const float4*>(io.rew_buf + i0);
+      const longlong2 p0 = *reinterpret_cast<const longlong2*>(io.progress_buf + i0);
+      const longlong2 p1 = *reinterpret_cast<const longlong2*>(io.progress_buf + i0 + 2);
+      bool d[4];
+      if (io.reset_elem_bytes == 1) {
+        const uint32_t m = *reinterpret_cast<const uint32_t*>(r8 + i0);
+        d[0] = (m & 0xFFu) != 0; d[1] = (m & 0xFF00u) != 0; d[2] = (m & 0xFF0000u) != 0; d[3] = (m & 0xFF000000u) != 0;
+      } else {
+        const longlong2 q0 = *reinterpret_cast<const longlong2*>(r64 + i0);
+        const longlong2 q1 = *reinterpret_cast<const longlong2*>(r64 + i0 + 2);
+        d[0] = q0.x != 0; d[1] = q0.y != 0; d[2] = q1.x != 0; d[3] = q1.y != 0;
+      }
+      const float rr[4] = {rw.x, rw.y, rw.z, rw.w};
+      const long long pp[4] = {p0.x, p0.y, p1.x, p1.y};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v[0] += (double)rr[k];
+        v[1] += d[k] ? 1.0 : 0.0;
+        v[2] += d[k] ? (double)pp[k] : 0.0;
+      }
+      if (io.successes) {
+        const float4 sc = *reinterpret_cast<const float4*>(io.successes + i0);
+        v[3] += ((double)sc.x + (double)sc.y) + ((double)sc.z + (double)sc.w);
+      }
+    } else {
+      for (int64_t i = i0; i < n; ++i) {
+        const bool dd = io.reset_elem_bytes == 1 ? r8[i] != 0 : r64[i] != 0;
+        v[0] += (double)io.rew_buf[i];
+        v[1] += dd ? 1.0 : 0.0;
+        v[2] += dd ? (double)io.progress_buf[i] : 0.0;
+        if (io.successes) v[3] += (double)io.successes[i];
+      }
+    }
   }
-  rew = block_sum(rew, lds);
-  done = block_sum(done, lds);
-  len = block_sum(len, lds);
-  succ = block_sum(succ, lds);
-  if (threadIdx.x == 0) {
-    double* p = io.partials + 4 * (int64_t)blockIdx.x;
-    p[0] = rew; p[1] = done; p[2] = len; p[3] = succ;
-  }
+  block_sum4<4>(v, lds);
+  if (threadIdx.x < 4) io.slots[4 * (int64_t)blockIdx.x + threadIdx.x] += v[threadIdx.x];
 }
 
-__global__ __launch_bounds__(STATS_THREADS) void episode_stats_fold_kernel(const oige_episode_stats_io io, int blocks, int64_t n) {
-  __shared__ double lds[STATS_THREADS / WAVE];
+// Workgroup b adds up slots [b * per_block, (b + 1) * per_block) in a fixed order -> out[4 b .. 4 b + 3]; the launch that
+// produces the final sums (one workgroup) also sets out[4] = env_steps.
+__global__ __launch_bounds__(STATS_THREADS) void episode_stats_fold_kernel(const double* __restrict__ slots, int64_t num_slots,
+                                                                           int64_t per_block, double* __restrict__ out,
+                                                                           double env_steps, int last) {
+  __shared__ double lds[4 * STATS_THREADS / WAVE];
   double t[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int b = threadIdx.x; b < blocks; b += STATS_THREADS)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) t[k] += io.partials[4 * (int64_t)b + k];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) t[k] = block_sum(t[k], lds);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) io.acc[k] += t[k];
-    io.acc[4] += (double)n;
+  const double2* s2 = reinterpret_cast<const double2*>(slots);
+  const int64_t lo_slot = (int64_t)blockIdx.x * per_block;
+  const int64_t hi_slot = lo_slot + per_block < num_slots ? lo_slot + per_block : num_slots;
+  for (int64_t b = lo_slot + threadIdx.x; b < hi_slot; b += STATS_THREADS) {
+    const double2 lo = s2[2 * b], hi = s2[2 * b + 1];
+    t[0] += lo.x; t[1] += lo.y; t[2] += hi.x; t[3] += hi.y;
   }
+  block_sum4<4>(t, lds);
+  if (threadIdx.x < 4) out[4 * (int64_t)blockIdx.x + threadIdx.x] = t[threadIdx.x];
+  if (last && threadIdx.x == 4) out[4] = env_steps;
 }
 
 }  // namespace oige
@@ -104,22 +140,50 @@ using namespace oige;
 extern "C" {
 
 int64_t oige_episode_stats_blocks(int64_t num_envs) {
-  const int64_t b = (num_envs + 4 * STATS_THREADS - 1) / (4 * STATS_THREADS);  // four envs per thread at least
+  const int64_t per = (int64_t)STATS_THREADS * STATS_ENVS_PER_THREAD;  // one pass of a workgroup
+  const int64_t b = (num_envs + per - 1) / per;
   return b < 1 ? 1 : (b > OIGE_EPISODE_STATS_MAX_BLOCKS ? OIGE_EPISODE_STATS_MAX_BLOCKS : b);
 }
 
 int oige_episode_stats_accumulate(const oige_episode_stats_io* io, int64_t num_envs, oige_stream_t stream) {
   OIGE_REQUIRE(io != nullptr, "episode_stats_accumulate: null io");
-  OIGE_REQUIRE(io->rew_buf && io->reset_buf && io->progress_buf && io->partials && io->acc, "episode_stats_accumulate: null pointer");
+  OIGE_REQUIRE(io->rew_buf && io->reset_buf && io->progress_buf && io->slots, "episode_stats_accumulate: null pointer");
   OIGE_REQUIRE(io->reset_elem_bytes == 1 || io->reset_elem_bytes == 8, "episode_stats_accumulate: reset_elem_bytes must be 1 (bool) or 8 (int64), not %d",
                io->reset_elem_bytes);
   OIGE_REQUIRE(num_envs >= 0, "episode_stats_accumulate: num_envs %lld out of range", (long long)num_envs);
+  OIGE_REQUIRE(aligned16(io->rew_buf) && aligned16(io->reset_buf) && aligned16(io->progress_buf) && aligned16(io->successes) &&
+                   aligned16(io->slots),
+               "episode_stats_accumulate: buffers must be 16-byte aligned");
   if (num_envs == 0) return OIGE_OK;
   const int blocks = (int)oige_episode_stats_blocks(num_envs);
-  hipLaunchKernelGGL(episode_stats_partial_kernel, dim3((unsigned)blocks), dim3(STATS_THREADS), 0, (hipStream_t)stream, *io, num_envs);
-  if (int rc = check_launch("episode_stats_partial_kernel")) return rc;
-  hipLaunchKernelGGL(episode_stats_fold_kernel, dim3(1), dim3(STATS_THREADS), 0, (hipStream_t)stream, *io, blocks, num_envs);
+  hipLaunchKernelGGL(episode_stats_accumulate_kernel, dim3((unsigned)blocks), dim3(STATS_THREADS), 0, (hipStream_t)stream, *io, num_envs);
+  return check_launch("episode_stats_accumulate_kernel");
+}
+
+int oige_episode_stats_fold(const double* slots, int64_t num_slots, double* acc, double env_steps, double* scratch,
+                            oige_stream_t stream) {
+  OIGE_REQUIRE(slots && acc, "episode_stats_fold: null pointer");
+  OIGE_REQUIRE(num_slots >= 0 && aligned16(slots) && aligned16(scratch), "episode_stats_fold: bad slot count / alignment");
+  hipStream_t s = (hipStream_t)stream;
+  // more than a workgroup's worth of slots (a slot per 64-env tile: 16384 at 1 M envs): two levels, 256 slots per workgroup
+  if (num_slots > 4 * STATS_THREADS) {
+    OIGE_REQUIRE(scratch != nullptr, "episode_stats_fold: %lld slots need the scratch buffer (oige_episode_stats_fold_scratch doubles)",
+                 (long long)num_slots);
+    const int64_t blocks = (num_slots + STATS_THREADS - 1) / STATS_THREADS;
+    OIGE_REQUIRE(blocks <= 4 * STATS_THREADS * STATS_THREADS, "episode_stats_fold: too many slots");
+    hipLaunchKernelGGL(episode_stats_fold_kernel, dim3((unsigned)blocks), dim3(STATS_THREADS), 0, s, slots, num_slots, (int64_t)STATS_THREADS,
+                       scratch, 0.0, 0);
+    if (int rc = check_launch("episode_stats_fold_kernel")) return rc;
+    slots = scratch;
+    num_slots = blocks;
+  }
+  hipLaunchKernelGGL(episode_stats_fold_kernel, dim3(1), dim3(STATS_THREADS), 0, s, slots, num_slots, num_slots > 0 ? num_slots : 1, acc,
+                     env_steps, 1);
   return check_launch("episode_stats_fold_kernel");
+}
+
+int64_t oige_episode_stats_fold_scratch(int64_t num_slots) {
+  return num_slots > 4 * STATS_THREADS ? 4 * ((num_slots + STATS_THREADS - 1) / STATS_THREADS) : 0;
 }
 
 int oige_observer_accumulate(const oige_observer_batch* batch, double* sums, int64_t* counts, oige_stream_t stream) {

@@ -125,8 +125,20 @@ class LocomotionTask(RLTask):
     def _buffers(self) -> _lib.LocomotionBuffers:
         vecs = self.materialize_vecs
         ts = (self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf, self.potentials, self.prev_potentials, self.actions,
-              self.up_vec if vecs else None, self.heading_vec if vecs else None, self._reset_workspace, self._tile_counts_u8)
+              self.up_vec if vecs else None, self.heading_vec if vecs else None, self._reset_workspace, self._tile_counts_u8,
+              self._stats_slots)
         return self._block("buffers", ts, (), self._build_buffers)
+
+    _stats_slots = None
+
+    def enable_episode_stats(self) -> torch.Tensor:
+        """Multi-GPU runs (utils/distributed.py: StatsReducer): the fused post kernel keeps this rank's episode statistics --
+        per 64-env tile {sum reward, done envs, sum of their episode lengths, 0} as running f64 sums -- in the returned
+        (tiles, 4) tensor: no launch and no traffic per step."""
+        if self._stats_slots is None:
+            tiles = max((self._num_envs + 63) // 64, 1)
+            self._stats_slots = torch.zeros((tiles, 4), dtype=torch.float64, device=self.obs_buf.device)
+        return self._stats_slots
 
     def _build_buffers(self) -> _lib.LocomotionBuffers:
         n, d = self._num_envs, self._robots.num_dof
@@ -149,6 +161,8 @@ class LocomotionTask(RLTask):
         b.actions = self.actions.data_ptr()
         b.reset_workspace = self._reset_workspace.data_ptr()
         b.tile_counts_u8 = self._tile_counts_u8.data_ptr()
+        if self._stats_slots is not None:
+            b.stats_slots = self._stats_slots.data_ptr()
         return b
 
     def _state(self) -> _lib.LocomotionState:

@@ -84,7 +84,7 @@ def test_every_entry_point_rejects_null_arguments_without_touching_the_gpu():
     crash, never a launch).  Validation runs before any HIP call, so this is safe without a device."""
     lib = _lib.load()
     pure = {"oige_version", "oige_num_tiles", "oige_workspace_ints", "oige_tile_counts_u8_bytes", "oige_last_error", "oige_compact_static_max_envs",
-            "oige_episode_stats_blocks"}
+            "oige_episode_stats_blocks", "oige_episode_stats_fold_scratch"}
     checked = 0
     for name, (res, args) in _lib.SIGNATURES.items():
         if name in pure:

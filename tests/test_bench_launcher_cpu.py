@@ -22,7 +22,7 @@ def _run(extra, env=None):
 
 
 def test_gpus_2_launches_two_ranks():
-    out, err = _run(["--gpus", "2", "--envs", "1000"])
+    out, err = _run(["--gpus", "2", "--envs", "1000", "--stats-every", "1"])
     assert "torch.distributed.run" in err  # the parent was the launcher
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["collective_backend"] == "gloo"
     st = out["config"]["episode_stats"]
@@ -45,6 +45,12 @@ def test_single_rank_needs_no_launcher():
     assert "torch.distributed.run" not in err
     assert out["n_gpus"] == 1 and out["ranks_seen"] == 1 and out["collective_backend"] == "none"
     assert "collective" not in out  # nothing to exchange at N = 1: no fold, no collective
+
+
+def test_default_cadence_is_one_collective_per_epoch():
+    out, _ = _run(["--gpus", "2", "--envs", "512"])  # 4 timed steps < the 16-step epoch: one collective, on the last step
+    assert out["collective"]["every"] == 4 and out["collective"]["calls_in_timed_region"] == 1
+    assert out["config"]["episode_stats"]["env_steps"] == 2 * 512 * 4
 
 
 def test_stats_every_k_steps():

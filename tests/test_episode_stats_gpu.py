@@ -1,5 +1,6 @@
-"""GPU: oige_episode_stats_accumulate (the device-side fold of StatsReducer) against torch's own sums of the same buffers.
-Counts are exact; the f64 sums of fp32 values agree to rounding of the summation order (rtol 1e-12)."""
+"""GPU: the device side of StatsReducer -- oige_episode_stats_accumulate / _fold, and the statistics slots the locomotion post
+kernel keeps itself -- against torch's own sums of the same buffers.  Counts are exact; the f64 sums of fp32 values agree to
+rounding of the summation order (rtol 1e-12)."""
 import pytest
 import torch
 
@@ -21,29 +22,63 @@ def _buffers(n, seed, bool_reset):
 @pytest.mark.parametrize("n", [1, 63, 257, 100003, 1 << 20])
 @pytest.mark.parametrize("bool_reset", [False, True])
 @pytest.mark.parametrize("with_successes", [False, True])
-def test_fold_matches_torch_sums(n, bool_reset, with_successes):
+def test_accumulate_and_fold_match_torch_sums(n, bool_reset, with_successes):
     red = od.StatsReducer("cuda")
     want = torch.zeros(5, dtype=torch.float64)
+    rew, reset, prog, succ = _buffers(n, 10 * n % 1000, bool_reset)
     for step in range(3):
-        rew, reset, prog, succ = _buffers(n, 10 * n % 1000 + step, bool_reset)
+        rew.mul_(1.25)  # same tensors (one argument block), new values every step
+        prog.add_(1)
         red.step(rew, reset, prog, succ if with_successes else None)
         want += od.local_stats(rew.cpu(), reset.cpu().long(), prog.cpu(), succ.cpu() if with_successes else None)
+    out = red.finish()  # folds the slots
     got = red.acc.cpu()
     assert got[1] == want[1] and got[2] == want[2] and got[4] == want[4] == 3 * n  # counts and integer sums: exact
     assert torch.allclose(got, want, rtol=1e-12, atol=1e-9), (got, want)
     assert red.latest is None and red.collectives == 0  # no process group: nothing was exchanged
-    out = red.finish()
     assert out["env_steps"] == 3 * n and out["num_envs"] == n
 
 
-def test_fold_is_deterministic_and_rejects_host_tensors():
+def test_accumulate_is_deterministic_and_rejects_host_tensors():
     rew, reset, prog, succ = _buffers(70001, 5, False)
     a, b = od.StatsReducer("cuda"), od.StatsReducer("cuda")
     for _ in range(2):
         a.step(rew, reset, prog, succ)
         b.step(rew, reset, prog, succ)
+    a.finish(), b.finish()
     assert torch.equal(a.acc, b.acc)  # fixed summation order: bit-identical
     from omniisaacgymenvs_amd import _lib
 
     with pytest.raises(_lib.OigeError):
         od.StatsReducer("cuda").step(rew.cpu(), reset, prog, succ)
+
+
+@pytest.mark.parametrize("name,n", [("Ant", 4096 + 37), ("Humanoid", 1000)])
+def test_locomotion_post_kernel_keeps_the_same_statistics(name, n):
+    """The fused post kernel's per-tile slots (oige_locomotion_buffers.stats_slots) == the standalone launch on its outputs."""
+    from helpers import make_task
+    from omniisaacgymenvs_amd.sim import workloads
+
+    env, task = make_task(name, n)
+    st = workloads.locomotion_state(n, task.dof_limits_lower.cpu(), task.dof_limits_upper.cpu(), task._num_sensors, device="cpu")
+    workloads.load_locomotion_state(task, st)
+    fused, plain = od.StatsReducer("cuda"), od.StatsReducer("cuda")
+    assert fused.attach(task) and fused._fused
+    actions = st["actions"].to(task.device)
+    for _ in range(3):
+        task.post_physics_step()
+        fused.step(task.rew_buf, task.reset_buf, task.progress_buf)
+        plain.step(task.rew_buf, task.reset_buf, task.progress_buf)
+        task.pre_physics_step(actions)
+    a, b = fused.finish(), plain.finish()
+    assert a["num_done"] == b["num_done"] > 0 and a["env_steps"] == b["env_steps"] == 3 * n
+    assert torch.equal(fused.acc[1:3], plain.acc[1:3])
+    assert torch.allclose(fused.acc, plain.acc, rtol=1e-12, atol=1e-9)
+    # the obs / reward / flags of a step do not depend on whether the slots are kept
+    env2, task2 = make_task(name, n)
+    workloads.load_locomotion_state(task2, st)
+    for t in (task, task2):
+        workloads.load_locomotion_state(t, st)
+        t.post_physics_step()
+    torch.cuda.synchronize()
+    assert torch.equal(task.obs_buf, task2.obs_buf) and torch.equal(task.rew_buf, task2.rew_buf) and torch.equal(task.reset_buf, task2.reset_buf)
