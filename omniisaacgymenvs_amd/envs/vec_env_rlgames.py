@@ -154,14 +154,18 @@ class VecEnvRLGames(VecEnvBase):
         if dr is not None and (t.randomize_actions or t.randomize_observations) and not dr.sync_free:
             raise RuntimeError("capture_step needs the sync-free randomizer (in-kernel Philox samples)")
         dev = t.obs_buf.device
+        # the graph of an earlier capture of this wrapper is released NOW, before the window opens (its destructor calls
+        # hipGraphExecDestroy, which HIP rejects while a capture is open)
+        self._graph = self._graph_out = None
         t._step_dev = torch.full((1,), getattr(t, "_step_count", 0), dtype=torch.int64, device=dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        t._capturing = True
-        if dr is not None:
-            dr.capturing = True
-        gc_on = quiesce_gc()
+        gc_on = None
         try:
+            t._capturing = True
+            if dr is not None:
+                dr.capturing = True
+            gc_on = quiesce_gc()
             with torch.cuda.stream(side):
                 t._step_dev += 1
                 self.step(actions)  # warm-up

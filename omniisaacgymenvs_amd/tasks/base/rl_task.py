@@ -181,12 +181,16 @@ class RLTask:
 
         dev = self.obs_buf.device
         _lib.require_device_tensor(actions, torch.float32, (self._num_envs, self.num_actions), "actions")
+        # graphs of an earlier capture of this task are released NOW, before the window opens (their destructors call
+        # hipGraphExecDestroy, which HIP rejects while a capture is open)
+        self._graph = self._graph_post = None
         self._step_dev = torch.full((1,), getattr(self, "_step_count", 0), dtype=torch.int64, device=dev)
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
-        self._capturing = True
-        gc_on = quiesce_gc()
+        gc_on = None
         try:
+            self._capturing = True
+            gc_on = quiesce_gc()
             with torch.cuda.stream(side):  # warm-up: one real step on the side stream
                 self._step_dev += 1
                 self.pre_physics_step(actions)

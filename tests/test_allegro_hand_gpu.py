@@ -84,8 +84,14 @@ def test_post_physics_matches_oracle(cfg_name, n, fused):
     ho.post_physics(spec, s, b)
     obs, rew, reset, extras = task.post_physics_step()
     torch.cuda.synchronize()
-    masked = int((~ok).sum())  # rows within 1e-6 of a decision threshold: none expected in this seeded state
-    assert masked <= (0 if n <= 1000 else 4), f"{masked} of {n} rows inside the threshold mask"
+    # rows within 1e-6 of a decision threshold are COUNTED, not excluded (census: profiles/r02/
+    # threshold_flips.json, 0 flips): the kernel evaluates rot_dist / goal_dist in the reference's operation order, so the
+    # flags must agree on every row
+    near = int((~ok).sum())
+    if near:
+        print(f"[threshold] {cfg_name} n={n}: {near} row(s) within 1e-6 of a decision threshold, compared like all others")
+    ok = torch.ones_like(ok)
+    masked = 0
     cons_in = torch.tensor([2.5])  # what _loaded put there before the step
     assert_equal(reset[ok], b.reset_buf[ok], "reset_buf")
     assert_equal(task.reset_goal_buf[ok], b.reset_goal_buf[ok], "reset_goal_buf")

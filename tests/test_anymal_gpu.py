@@ -217,6 +217,27 @@ def test_full_size_properties():
     assert bool((task.rew_buf >= 0).all())
 
 
+def test_full_size_matches_the_oracle():
+    """C5's per-GPU size (2 M envs / 8 GPUs = 262144) against the ORACLE, not only closed forms -- the whole step
+    (flags, ids, curriculum with its whole-matrix command norm over all ~29 000 reset envs, the 140-point height scan with its
+    Philox noise, reward, episode sums, extras means, reset rows).  The oracle takes a few seconds at this size, so every
+    row is compared, not a slice: the curriculum norm and the extras means couple all the envs of a step."""
+    n = 1 << 18
+    env, task, st = _loaded(n)
+    task._anymals.apply_resets = False
+    spec = _spec(task)
+    s, b = _oracle_inputs(task, st)
+    seed, step = task._rand_seed, task._step_count + 1
+    env_ids, view = ao.post_physics(spec, b, s, task.height_samples.cpu(), task.terrain_origins.cpu(),
+                                    draw=_philox_draws(seed, step), noise_u=_philox_noise(n, seed, step))
+    task.post_physics_step()
+    torch.cuda.synchronize()
+    assert 0.05 * n < len(env_ids) < 0.3 * n
+    _compare(task, b, env_ids, view, n)
+    lv = task.terrain_levels.cpu()[env_ids]
+    assert len(torch.unique(lv)) > 3  # the curriculum really moved envs in both directions
+
+
 def test_device_side_push_robots_over_several_steps():
     """push_robots (:419-420, :446-450) inside the post kernel: on steps where common_step_counter % push_interval == 0 the
     base xy velocities of EVERY env become U(-1,1) (Philox stream 7) before anything reads them, so that step's

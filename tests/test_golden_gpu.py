@@ -39,7 +39,7 @@ def test_locomotion_hip_reproduces_golden(kind, name, fused):
         assert_close(obs, g["out_obs"], f"{tag} obs")
         assert_close(task.up_vec, g["out_up_vec"], f"{tag} up_vec")
         assert_close(task.heading_vec, g["out_heading_vec"], f"{tag} heading_vec")
-        assert_close(rew, g["out_rew"], f"{tag} rew", mask=(g["out_obs"][:, 10] - 0.93).abs() > 1e-6)
+        assert_close(rew, g["out_rew"], f"{tag} rew")  # every row: the golden files hold up_proj = 0.93 +- 1 ulp rows on purpose
 
 
 @pytest.mark.parametrize("fused", [True, False])

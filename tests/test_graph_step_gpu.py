@@ -231,3 +231,64 @@ def test_wrapper_capture_equals_eager_env_steps(cfg, n):
     oe, _, _, _ = ee.step(acts[2].clone())
     torch.cuda.synchronize()
     assert_equal(og["obs"], oe["obs"], "obs after a mixed eager/replay sequence")
+
+
+def test_capture_survives_dropped_graphs_and_restores_gc():
+    """a CUDAGraph destroyed while another capture is open ends the process (hipGraphExecDestroy is rejected
+    inside a capture window; SIGABRT from a destructor).  Two ways a graph can die there: (a) the cyclic collector frees an
+    older graph that sat in a reference cycle -- capture_step collects and switches the collector off around the window
+    (quiesce_gc); (b) a second capture_step on the SAME task rebinds task._graph -- the old graph is now released before the
+    window opens.  Both are provoked here; the process must survive, replay must equal eager steps, gc must be back on."""
+    import gc
+
+    n = 256
+    a = _build("Ant", n, "device")
+    acts = (torch.rand(n, a.task.num_actions, generator=torch.Generator().manual_seed(1)) * 2 - 1).to("cuda:0")
+    a.task.capture_step(acts.clone())
+    a.task.replay_step()
+    torch.cuda.synchronize()
+
+    class Holder:  # (a): the captured graph of task A in a reference cycle, then dropped
+        pass
+
+    h = Holder()
+    h.me, h.graph = h, a.task._graph
+    a.task._graph = None
+    del h
+    gc.disable()  # garbage stays where it is until capture_step itself decides what to do with it
+    try:
+        b = _build("Humanoid", n, "device")
+        acts_b = (torch.rand(n, b.task.num_actions, generator=torch.Generator().manual_seed(2)) * 2 - 1).to("cuda:0")
+        b.task.capture_step(acts_b.clone())
+        assert not gc.isenabled()  # quiesce_gc left the collector the way it found it
+    finally:
+        gc.enable()
+    b.task.replay_step()
+    old = b.task._graph
+    b.task.capture_step(acts_b.clone())  # (b): re-capture on the same task
+    assert b.task._graph is not old and gc.isenabled()
+    del old
+    # replay == eager after all of that
+    e = _build("Humanoid", n, True)
+    static = b.task._graph_actions
+    e.task.pre_physics_step(acts_b); e.task.post_physics_step()      # warm-up step of the 1st capture
+    e.task.pre_physics_step(acts_b); e.task.post_physics_step()      # the replay above
+    e.task.pre_physics_step(acts_b); e.task.post_physics_step()      # warm-up step of the 2nd capture
+    static.copy_(acts_b)
+    b.task.replay_step()
+    e.task.pre_physics_step(acts_b); e.task.post_physics_step()
+    torch.cuda.synchronize()
+    A_, B_ = _tensors(e.task), _tensors(b.task)
+    for key in A_:
+        assert_equal(B_[key], A_[key], key)
+
+    # an exception inside the window leaves neither the capturing flag nor the collector in the wrong state
+    c = _build("Ant", n, "device")
+
+    def boom(_actions):
+        raise RuntimeError("boom")
+
+    c.task.pre_physics_step = boom
+    with pytest.raises(RuntimeError, match="boom"):
+        c.task.capture_step(acts.clone())
+    assert c.task._capturing is False and gc.isenabled()

