@@ -484,6 +484,47 @@ int oige_anymal_post_physics(const oige_anymal_params* params, const oige_anymal
                              const oige_anymal_buffers* buffers, const oige_anymal_reset_io* reset_io,
                              int64_t num_envs, oige_stream_t stream);
 
+/* The same step, stage by stage: the reference's post_physics_step (:409-444) calls check_termination (:452-466),
+ * calculate_metrics (:468-533) and get_observations (:535-552) as methods of their own, after computing the body-frame
+ * quantities inline (:421-427) and keeping them as attributes.  `stages` is any subset of
+ *   PROGRESS     progress_buf += 1                                                          (:410)
+ *   FRAME        base_lin_vel / base_ang_vel / projected_gravity -> `frame`, commands[:, 2] (:421-427)
+ *   TERMINATION  timeout_buf, has_fallen, reset_buf (bool), the per-tile reset counts       (:452-466)
+ *   METRICS      rew_buf, episode_sums; reads `frame`, reset_buf, has_fallen, timeout_buf   (:468-533)
+ *   OBS          obs_buf WITHOUT noise (heights from the current view state); reads `frame` (:535-552)
+ * executed in that order; OIGE_ANYMAL_STAGE_ALL is oige_anymal_post_physics (which also runs the in-step reset_idx, the
+ * observation noise and the last_* copies: RESET / NOISE / LAST exist only inside the fused step; on their own they are
+ * oige_anymal_reset_idx and the reference's own two elementwise lines, :438-442).  `frame` is required for FRAME / METRICS /
+ * OBS and optional for ALL (NULL: the three tensors are not materialised).  Split == fused bit for bit
+ * (tests/test_anymal_gpu.py::test_split_stage_methods_match_fused).                                               */
+#define OIGE_ANYMAL_STAGE_PROGRESS 1u
+#define OIGE_ANYMAL_STAGE_FRAME 2u
+#define OIGE_ANYMAL_STAGE_TERMINATION 4u
+#define OIGE_ANYMAL_STAGE_METRICS 8u
+#define OIGE_ANYMAL_STAGE_RESET 16u
+#define OIGE_ANYMAL_STAGE_OBS 32u
+#define OIGE_ANYMAL_STAGE_NOISE 64u
+#define OIGE_ANYMAL_STAGE_LAST 128u
+#define OIGE_ANYMAL_STAGE_ALL 255u
+
+typedef struct oige_anymal_frame { /* (N,3) each: self.base_lin_vel, self.base_ang_vel, self.projected_gravity (:422-424) */
+  float* base_lin_vel;
+  float* base_ang_vel;
+  float* projected_gravity;
+} oige_anymal_frame;
+
+int oige_anymal_post_physics_stages(const oige_anymal_params* params, const oige_anymal_state* state,
+                                    const oige_anymal_buffers* buffers, const oige_anymal_reset_io* reset_io,
+                                    const oige_anymal_frame* frame, int64_t num_envs, uint32_t stages, oige_stream_t stream);
+
+/* update_terrain_level(env_ids) on its own (:369-380; inside a step reset_idx runs it in the head kernel):
+ * distance of each id's root from its env origin against the whole-matrix norm of ALL the ids' xy commands (:376),
+ * level -= / += / clip / % env_rows, env_origins[ids] = terrain_origins[level, type].  No-op unless init_done and curriculum. */
+int oige_anymal_update_terrain_level(const oige_anymal_params* params, const float* root_pos /* (N,3) */,
+                                     const float* terrain_origins, const float* commands /* (N,4) */,
+                                     int64_t* terrain_levels, const int64_t* terrain_types, float* env_origins,
+                                     const int64_t* env_ids, int64_t num_ids, int64_t num_envs, oige_stream_t stream);
+
 /* reset_idx(env_ids) on its own (:318-367; post_reset :314-315 calls it with every env and
  * init_done = 0): env_ids are given as the byte mask reset_io->reset_mask; same outputs.          */
 int oige_anymal_reset_idx(const oige_anymal_params* params, const oige_anymal_state* state,

@@ -157,6 +157,14 @@ class AnymalResetIO(C.Structure):
     ]) + [("step_ptr", _fp), ("push_velocities", _fp), ("push_count", _fp), ("push_interval", C.c_int64), ("push_offset", C.c_int64)]
 
 
+class AnymalFrame(C.Structure):
+    _fields_ = [("base_lin_vel", _fp), ("base_ang_vel", _fp), ("projected_gravity", _fp)]
+
+
+(ANYMAL_STAGE_PROGRESS, ANYMAL_STAGE_FRAME, ANYMAL_STAGE_TERMINATION, ANYMAL_STAGE_METRICS, ANYMAL_STAGE_RESET, ANYMAL_STAGE_OBS,
+ ANYMAL_STAGE_NOISE, ANYMAL_STAGE_LAST, ANYMAL_STAGE_ALL) = 1, 2, 4, 8, 16, 32, 64, 128, 255
+
+
 class AnymalFlatParams(C.Structure):
     _fields_ = [
         ("lin_vel_scale", _f), ("ang_vel_scale", _f), ("dof_pos_scale", _f), ("dof_vel_scale", _f), ("action_scale", _f),
@@ -445,6 +453,9 @@ SIGNATURES = {
                                            C.POINTER(AnymalResetIO), C.c_int64, _P]),
     "oige_anymal_reset_idx": (C.c_int, [C.POINTER(AnymalParams), C.POINTER(AnymalState), C.POINTER(AnymalBuffers),
                                         C.POINTER(AnymalResetIO), C.c_int64, _P]),
+    "oige_anymal_post_physics_stages": (C.c_int, [C.POINTER(AnymalParams), C.POINTER(AnymalState), C.POINTER(AnymalBuffers),
+                                                  C.POINTER(AnymalResetIO), C.POINTER(AnymalFrame), C.c_int64, C.c_uint32, _P]),
+    "oige_anymal_update_terrain_level": (C.c_int, [C.POINTER(AnymalParams), _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int64, _P]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -41,6 +41,9 @@ struct AnymalPost {
   // (b.tile_counts_u8) and one partial sum of the command norm per GROUP in the workspace's group-offset slots; a head wave
   // that holds a reset env sums both itself, and the last tile's wave leaves the total where the scan would have.
   int unscanned;
+  // individually callable stages (oige_anymal_post_physics_stages): 0 = the fused step, else a mask of OIGE_ANYMAL_STAGE_*
+  uint32_t stages;
+  oige_anymal_frame x;  // base_lin_vel / base_ang_vel / projected_gravity as tensors of their own (optional in the fused step)
 };
 
 // wrap_to_pi AS TORCHSCRIPT RUNS IT (:615-619): `angles %= 2*pi` of a scripted function is aten::fmod_
@@ -110,9 +113,13 @@ __global__ __launch_bounds__(GROUP) void anymal_flags_kernel(const AnymalPost a)
     }
     if (env == 0) *a.r.push_count = pushing ? a.n : 0;
   }
-  if (live && a.mode == 0) {
-    const int64_t progress = a.b.progress_buf[env] + 1;  // :410
-    a.b.progress_buf[env] = progress;
+  const bool st_progress = a.stages == 0 || (a.stages & OIGE_ANYMAL_STAGE_PROGRESS);
+  const bool st_term = a.stages == 0 || (a.stages & OIGE_ANYMAL_STAGE_TERMINATION);
+  if (live && a.mode == 0 && !st_term) {  // progress += 1 on its own (:410)
+    if (st_progress) a.b.progress_buf[env] += 1;
+  } else if (live && a.mode == 0) {
+    const int64_t progress = a.b.progress_buf[env] + (st_progress ? 1 : 0);  // :410
+    if (st_progress) a.b.progress_buf[env] = progress;
     const bool timeout = progress >= (int64_t)a.p.max_episode_length - 1;  // :453-457
     const float4* kc = reinterpret_cast<const float4*>(a.s.knee_contact + env * 12);
     const float4 k0 = kc[0], k1 = kc[1], k2 = kc[2];
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(GROUP) void anymal_flags_kernel(const AnymalPost a)
     const float2 c = *reinterpret_cast<const float2*>(a.b.commands + env * 4);
     cmd2 = c.x * c.x + c.y * c.y;
   }
+  if (a.mode == 0 && !st_term) return;  // (uniform) nothing was flagged: the counts stay what they are
   const unsigned long long m = __ballot(reset);
   const float s = wave_sum_ff(cmd2);
   if (lane_id() == 0) {
@@ -237,7 +245,9 @@ __device__ __forceinline__ void anymal_noise4(const oige_anymal_reset_io& r, uin
   }
 }
 
-template <bool FULLTILE, bool NOISE_IN>
+// SPLIT: a.stages selects FRAME / METRICS / OBS (the individually callable methods of the reference; never the in-step reset,
+// which is reset_idx(env_ids) = mode 1).  The fused step is its own instantiation: every test below folds away in it.
+template <bool FULLTILE, bool NOISE_IN, bool SPLIT = false>
 __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __restrict__ lds, int64_t t, int nv) {
   float* rows = lds;                         // 64 x 52
   float* s_ns = lds + TILE * ARW;            // noise_scale_vec (:157-171) of observation columns 0:36 (48 slots kept)
@@ -249,6 +259,10 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
   float* pose_out = a.b.reduce_workspace + pose_offset(T) + env0 * APOSE;
 
   const bool step = a.mode == 0;
+  const bool do_frame = !SPLIT || (a.stages & OIGE_ANYMAL_STAGE_FRAME);
+  const bool do_metrics = !SPLIT || (a.stages & OIGE_ANYMAL_STAGE_METRICS);
+  const bool do_obs = !SPLIT || (a.stages & OIGE_ANYMAL_STAGE_OBS);
+  constexpr bool do_reset = !SPLIT;
   // ---- A/B: the six 12-wide arrays, lane-linear, into row columns (12 % 4 == 0: a float4 never straddles rows)
   if (step) {
     Chunk<AD> c0, c1, c2;
@@ -282,19 +296,36 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
     }
     const float4 cm = *reinterpret_cast<const float4*>(a.b.commands + env * 4);
     float cmd[4] = {cm.x, cm.y, cm.z, cm.w};
-    const bool reset = live && (step ? a.b.reset_buf[env] : a.r.reset_mask[env]) != 0;
+    const bool flagged = live && (step ? a.b.reset_buf[env] : a.r.reset_mask[env]) != 0;  // reset_buf, as the reward reads it
+    const bool reset = do_reset && flagged;                                                // ... and as the in-step reset does
     const bool has_fallen = step && a.b.has_fallen[env] != 0;
     const int64_t timeout = step ? a.b.timeout_buf[env] : 0;
 
     // frame quantities (:422-427)
-    const f3 lin = quat_rotate_inverse(bq, f3{v0.x, v0.y, v1.x});
-    const f3 ang = quat_rotate_inverse(bq, f3{v1.y, v2.x, v2.y});
-    const f3 grav = quat_rotate_inverse(bq, f3{0.0f, 0.0f, -1.0f});
-    const f3 fwd = quat_apply(bq, f3{1.0f, 0.0f, 0.0f});
-    const float heading = atan2f(fwd.y, fwd.x);
-    {
+    f3 lin, ang, grav;
+    if (do_frame) {
+      lin = quat_rotate_inverse(bq, f3{v0.x, v0.y, v1.x});
+      ang = quat_rotate_inverse(bq, f3{v1.y, v2.x, v2.y});
+      grav = quat_rotate_inverse(bq, f3{0.0f, 0.0f, -1.0f});
+      const f3 fwd = quat_apply(bq, f3{1.0f, 0.0f, 0.0f});
+      const float heading = atan2f(fwd.y, fwd.x);
       const float w = 0.5f * wrap_to_pi(cmd[3] - heading);
       if (step) cmd[2] = (w != w) ? w : (w < -1.0f ? -1.0f : (w > 1.0f ? 1.0f : w));
+      if (a.x.base_lin_vel && live) {  // the reference keeps them as attributes (:422-424)
+        float* o0 = a.x.base_lin_vel + env * 3;
+        float* o1 = a.x.base_ang_vel + env * 3;
+        float* o2 = a.x.projected_gravity + env * 3;
+        o0[0] = lin.x; o0[1] = lin.y; o0[2] = lin.z;
+        o1[0] = ang.x; o1[1] = ang.y; o1[2] = ang.z;
+        o2[0] = grav.x; o2[1] = grav.y; o2[2] = grav.z;
+      }
+    } else {  // a later stage on its own reads what the FRAME stage left (calculate_metrics / get_observations use the attributes)
+      const float* i0 = a.x.base_lin_vel + env * 3;
+      const float* i1 = a.x.base_ang_vel + env * 3;
+      const float* i2 = a.x.projected_gravity + env * 3;
+      lin = f3{i0[0], i0[1], i0[2]};
+      ang = f3{i1[0], i1[1], i1[2]};
+      grav = f3{i2[0], i2[1], i2[2]};
     }
 
     // calculate_metrics (:468-533)
@@ -359,14 +390,14 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
     rew += rew_torque; rew += rew_joint_acc; rew += rew_action_rate; rew += rew_hip; rew += rew_fallen_over;
     rew = (rew != rew) ? rew : (rew < 0.0f ? 0.0f : rew);  // torch.clip(min=0)
     // `termination * reset_buf * ~timeout_buf`: bitwise NOT of an int64 0/1 (:521) -> -1 / -2
-    rew += (rs[OIGE_AR_TERMINATION] * (reset ? 1.0f : 0.0f)) * (float)(~timeout);
+    rew += (rs[OIGE_AR_TERMINATION] * (flagged ? 1.0f : 0.0f)) * (float)(~timeout);
 
     // episode sums (:524-533); dict order :68-82 -> row index
     float es[AE];
-    if (live) {
+    if (live && (do_metrics || do_reset)) {
 #pragma unroll
       for (int k = 0; k < AE; ++k) es[k] = a.b.episode_sums[(int64_t)k * a.n + env];
-      if (step) {
+      if (step && do_metrics) {
         es[0] += rew_lin_vel_xy; es[2] += rew_ang_vel_z; es[1] += rew_lin_vel_z; es[3] += rew_ang_vel_xy;
         es[4] += rew_orient; es[5] += rew_torque; es[6] += rew_joint_acc; es[11] += rew_action_rate;
         es[7] += rew_base_height; es[12] += rew_hip;
@@ -384,7 +415,7 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
     int64_t k_front = 0;   // flagged envs in front of this tile's group
     float gnorm_own = 0.f;  // whole-matrix norm of the reset envs' xy commands (:376)
     const bool last_tile = t == T - 1;
-    if (a.unscanned && (rmask != 0 || last_tile)) {  // (wave-uniform) what the scan / norm launch would have left
+    if (do_reset && a.unscanned && (rmask != 0 || last_tile)) {  // (wave-uniform) what the scan / norm launch would have left
       const int64_t g = t / GROUP_TILES, G = num_groups(a.n);
       int front = (int)u8_words_partial<WAVE, 2>(a.b.tile_counts_u8, g, lane_id());  // (two chunks in flight: the kernel sits at 124 VGPRs)
       const float* gp = reinterpret_cast<const float*>(a.b.reset_workspace + padded_tiles(a.n));  // one partial sum per group
@@ -505,7 +536,7 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
       a.r.env_ids[k] = env;
     }
     // per-tile sums for extras (:361-367): episode sums of the reset envs BEFORE they are zeroed
-    {
+    if (do_reset) {
       // the 14 wave sums advance together, one butterfly step at a time: 14 independent cross-lane moves in flight per
       // step instead of 14 dependent chains of six (the same additions in the same order per sum)
       float part[AE + 1];
@@ -529,13 +560,15 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
         if (reset) es[k] = 0.0f;  // :366
     }
     if (live) {
+      if (do_metrics || do_reset) {
 #pragma unroll
-      for (int k = 0; k < AE; ++k) a.b.episode_sums[(int64_t)k * a.n + env] = es[k];
-      if (step) a.b.rew_buf[env] = rew;
-      if (step || reset) *reinterpret_cast<float4*>(a.b.commands + env * 4) = make_float4(cmd[0], cmd[1], cmd[2], cmd[3]);
+        for (int k = 0; k < AE; ++k) a.b.episode_sums[(int64_t)k * a.n + env] = es[k];
+      }
+      if (step && do_metrics) a.b.rew_buf[env] = rew;
+      if ((step && do_frame) || reset) *reinterpret_cast<float4*>(a.b.commands + env * 4) = make_float4(cmd[0], cmd[1], cmd[2], cmd[3]);
       // last_actions[:] = actions[:]; last_dof_vel[:] = dof_vel[:] -- the view row already holds the reset
       // velocities, so reset envs end the step with the NEW dof_vel, not 0 (:355 overwritten by :442)
-      if (step || reset) {  // standalone reset_idx: last_actions = last_dof_vel = 0 for env_ids (:354-355)
+      if (do_reset && (step || reset)) {  // standalone reset_idx: last_actions = last_dof_vel = 0 for env_ids (:354-355)
         float4* lao = reinterpret_cast<float4*>(a.b.last_actions + env * AD);
         float4* ldo = reinterpret_cast<float4*>(a.b.last_dof_vel + env * AD);
         const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -546,7 +579,7 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
         }
       }
     }
-    if (step) {
+    if (step && do_obs) {
       // observation head (:540-550), in place over the row's first 36 columns
       *reinterpret_cast<float4*>(row + 0) = make_float4(lin.x * p.lin_vel_scale, lin.y * p.lin_vel_scale, lin.z * p.lin_vel_scale,
                                                         ang.x * p.ang_vel_scale);
@@ -571,7 +604,7 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
       }
     }
   }
-  if (!step) return;  // uniform across the workgroup
+  if (!step || !do_obs) return;  // uniform across the workgroup
   // The action columns of the observation (176:188) are a copy of `actions` (their noise scale is zero, :170: obs +
   // (2u - 1) * 0 is obs, no draw).  The tile's actions are fetched again here, lane-linear and L2-hot, BEFORE the epilogue's
   // first store: a load issued after a store waits for that store's round trip (loads and stores share vmcnt).
@@ -619,6 +652,11 @@ __global__ __launch_bounds__(WAVE) void anymal_head_kernel(const AnymalPost a) {
   const int64_t t = blockIdx.x;
   const int64_t left = a.n - t * TILE;
   const bool noise_in = a.r.noise_u != nullptr;
+  if (a.stages != 0) {  // individually called stages: one generic instantiation, off the hot path
+    if (noise_in) anymal_head_tile<false, true, true>(a, lds, t, left >= TILE ? TILE : (int)left);
+    else anymal_head_tile<false, false, true>(a, lds, t, left >= TILE ? TILE : (int)left);
+    return;
+  }
   if (left >= TILE) {
     if (noise_in) anymal_head_tile<true, true>(a, lds, t, TILE);
     else anymal_head_tile<true, false>(a, lds, t, TILE);
@@ -872,7 +910,7 @@ __global__ __launch_bounds__(ANT) void anymal_scan_kernel(const AnymalPost a) {
   __shared__ __align__(16) float s_strip[(ANT / WAVE) * 256];
   if (blockIdx.x == 0) {
     static_assert(sizeof(double) * (ANT / WAVE) * (AE + 1) <= sizeof(float) * TILE * AER, "extras partials fit in s_env");
-    anymal_extras_body<ANT>(a, reinterpret_cast<double (*)[AE + 1]>(s_env));
+    if (a.stages == 0) anymal_extras_body<ANT>(a, reinterpret_cast<double (*)[AE + 1]>(s_env));  // (get_observations alone resets nothing)
     return;
   }
   const int64_t t = (int64_t)blockIdx.x - 1;
@@ -885,6 +923,50 @@ __global__ __launch_bounds__(ANT) void anymal_scan_kernel(const AnymalPost a) {
   else if (hmin) anymal_scan_tile<false, true, true>(a, s_env, s_k, s_strip, t, nv);
   else if (!noise_in) anymal_scan_tile<false, false, false>(a, s_env, s_k, s_strip, t, nv);
   else anymal_scan_tile<false, false, true>(a, s_env, s_k, s_strip, t, nv);
+}
+
+// update_terrain_level(env_ids) on its own (:369-380; reset_idx runs it inside the head kernel).  One workgroup: the
+// whole-matrix norm of the ids' xy commands first (torch.norm over ALL of them, :376; f64 partials in thread order), then
+// every id's level and origin.  A few thousand ids at most per call in the reference's regime; latency-bound.
+__global__ __launch_bounds__(1024) void anymal_terrain_level_kernel(const oige_anymal_params p, const float* __restrict__ root_pos,
+                                                                    const float* __restrict__ terrain_origins,
+                                                                    const float* __restrict__ commands,
+                                                                    int64_t* __restrict__ terrain_levels,
+                                                                    const int64_t* __restrict__ terrain_types,
+                                                                    float* __restrict__ env_origins, const int64_t* __restrict__ env_ids,
+                                                                    int64_t num_ids, int64_t n) {
+  __shared__ double part[1024 / WAVE];
+  __shared__ float s_norm;
+  double acc = 0.0;
+  for (int64_t k = threadIdx.x; k < num_ids; k += 1024) {
+    const int64_t i = env_ids[k];
+    if (i < 0 || i >= n) continue;
+    const float2 c = *reinterpret_cast<const float2*>(commands + i * 4);
+    acc += (double)(c.x * c.x) + (double)(c.y * c.y);
+  }
+#pragma unroll
+  for (int off = WAVE / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, WAVE);
+  if (lane_id() == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 1024 / WAVE; ++w) t += part[w];
+    s_norm = __builtin_sqrtf((float)t);
+  }
+  __syncthreads();
+  const float gnorm = s_norm;
+  for (int64_t k = threadIdx.x; k < num_ids; k += 1024) {
+    const int64_t i = env_ids[k];
+    if (i < 0 || i >= n) continue;
+    const float dist = norm3(f3{root_pos[i * 3] - env_origins[i * 3], root_pos[i * 3 + 1] - env_origins[i * 3 + 1], 0.0f});  // :375
+    int64_t level = terrain_levels[i];
+    level -= dist < (gnorm * p.max_episode_length_s) * 0.25f ? 1 : 0;  // :376
+    level += dist > p.half_env_length ? 1 : 0;                          // :377
+    level = (level < 0 ? 0 : level) % p.env_rows;                       // :378
+    terrain_levels[i] = level;
+    const float* to = terrain_origins + (level * p.env_cols + terrain_types[i]) * 3;  // :379
+    env_origins[i * 3] = to[0]; env_origins[i * 3 + 1] = to[1]; env_origins[i * 3 + 2] = to[2];
+  }
 }
 
 // stand-alone extras for reset_idx(env_ids) (no scan there)
@@ -936,8 +1018,22 @@ int oige_anymal_torques_clone(const oige_anymal_params* params, const float* act
 
 static int anymal_launch(const oige_anymal_params* params, const oige_anymal_state* state,
                          const oige_anymal_buffers* buffers, const oige_anymal_reset_io* reset_io, int64_t num_envs,
-                         int mode, oige_stream_t stream) {
+                         int mode, oige_stream_t stream, uint32_t stages = 0, const oige_anymal_frame* frame = nullptr) {
   OIGE_REQUIRE(params && state && buffers && reset_io, "anymal: null struct pointer");
+  OIGE_REQUIRE((stages & ~OIGE_ANYMAL_STAGE_ALL) == 0, "anymal_post_physics_stages: bad stages mask 0x%x", stages);
+  if (stages == OIGE_ANYMAL_STAGE_ALL) stages = 0;  // every stage = the fused step
+  OIGE_REQUIRE(stages == 0 || !(stages & (OIGE_ANYMAL_STAGE_RESET | OIGE_ANYMAL_STAGE_NOISE | OIGE_ANYMAL_STAGE_LAST)),
+               "anymal_post_physics_stages: RESET / NOISE / LAST only run inside the fused step (all stages); on their own they are "
+               "reset_idx(env_ids) = oige_anymal_reset_idx and two elementwise torch lines (anymal_terrain.py:438-442)");
+  const bool head_split = stages & (OIGE_ANYMAL_STAGE_FRAME | OIGE_ANYMAL_STAGE_METRICS | OIGE_ANYMAL_STAGE_OBS);
+  if (frame) {
+    const bool any = frame->base_lin_vel || frame->base_ang_vel || frame->projected_gravity;
+    OIGE_REQUIRE(!any || (frame->base_lin_vel && frame->base_ang_vel && frame->projected_gravity),
+                 "anymal: pass all three frame tensors or none");
+  }
+  if (head_split)
+    OIGE_REQUIRE(frame && frame->base_lin_vel, "anymal_post_physics_stages: FRAME / METRICS / OBS on their own need the frame tensors "
+                                               "(base_lin_vel, base_ang_vel, projected_gravity)");
   OIGE_REQUIRE(num_envs >= 0 && num_envs < ((int64_t)1 << 31) / 256, "anymal: num_envs %lld out of range", (long long)num_envs);
   const oige_anymal_state& s = *state;
   const oige_anymal_buffers& b = *buffers;
@@ -977,9 +1073,27 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
   a.r = r;
   a.n = num_envs;
   a.mode = mode;
+  a.stages = stages;
+  a.x = frame ? *frame : oige_anymal_frame{nullptr, nullptr, nullptr};
   hipStream_t st = (hipStream_t)stream;
   const int64_t G = num_groups(num_envs), T = num_tiles(num_envs);
   a.unscanned = (b.tile_counts_u8 && G <= UNSCANNED_U8_MAX_GROUPS) ? 1 : 0;
+  if (stages != 0) {  // individually callable stages, in the reference's order (anymal_terrain.py:410-437)
+    if (stages & (OIGE_ANYMAL_STAGE_PROGRESS | OIGE_ANYMAL_STAGE_TERMINATION)) {
+      hipLaunchKernelGGL(anymal_flags_kernel, dim3((unsigned)G), dim3(GROUP), 0, st, a);
+      if (int rc = check_launch("anymal_flags_kernel")) return rc;
+    }
+    if (head_split) {
+      if (stages & OIGE_ANYMAL_STAGE_OBS) a.p.add_noise = 0;  // get_observations adds none (:535-552); :438-439 is the caller's line
+      hipLaunchKernelGGL(anymal_head_kernel, dim3((unsigned)T), dim3(WAVE), 0, st, a);
+      if (int rc = check_launch("anymal_head_kernel")) return rc;
+      if (stages & OIGE_ANYMAL_STAGE_OBS) {
+        hipLaunchKernelGGL(anymal_scan_kernel, dim3((unsigned)T + 1), dim3(ANT), 0, st, a);
+        return check_launch("anymal_scan_kernel");
+      }
+    }
+    return OIGE_OK;
+  }
   hipLaunchKernelGGL(anymal_flags_kernel, dim3((unsigned)G), dim3(GROUP), 0, st, a);
   if (int rc = check_launch("anymal_flags_kernel")) return rc;
   if (!a.unscanned) {
@@ -1007,6 +1121,27 @@ int oige_anymal_reset_idx(const oige_anymal_params* params, const oige_anymal_st
                           const oige_anymal_buffers* buffers, const oige_anymal_reset_io* reset_io, int64_t num_envs,
                           oige_stream_t stream) {
   return anymal_launch(params, state, buffers, reset_io, num_envs, 1, stream);
+}
+
+int oige_anymal_post_physics_stages(const oige_anymal_params* params, const oige_anymal_state* state,
+                                    const oige_anymal_buffers* buffers, const oige_anymal_reset_io* reset_io,
+                                    const oige_anymal_frame* frame, int64_t num_envs, uint32_t stages, oige_stream_t stream) {
+  OIGE_REQUIRE(stages != 0, "anymal_post_physics_stages: empty stages mask");
+  return anymal_launch(params, state, buffers, reset_io, num_envs, 0, stream, stages, frame);
+}
+
+int oige_anymal_update_terrain_level(const oige_anymal_params* params, const float* root_pos, const float* terrain_origins,
+                                     const float* commands, int64_t* terrain_levels, const int64_t* terrain_types,
+                                     float* env_origins, const int64_t* env_ids, int64_t num_ids, int64_t num_envs,
+                                     oige_stream_t stream) {
+  OIGE_REQUIRE(params && root_pos && terrain_origins && commands && terrain_levels && terrain_types && env_origins,
+               "anymal_update_terrain_level: null pointer");
+  OIGE_REQUIRE(num_ids >= 0 && num_envs >= 0 && num_ids <= num_envs && (num_ids == 0 || env_ids), "anymal_update_terrain_level: bad ids");
+  OIGE_REQUIRE(params->env_rows >= 1 && params->env_cols >= 1, "anymal_update_terrain_level: bad terrain dimensions");
+  if (num_ids == 0 || !params->init_done || !params->curriculum) return OIGE_OK;  // :370-372
+  hipLaunchKernelGGL(anymal_terrain_level_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *params, root_pos, terrain_origins, commands,
+                     terrain_levels, terrain_types, env_origins, env_ids, num_ids, num_envs);
+  return check_launch("anymal_terrain_level_kernel");
 }
 
 }  // extern "C"

@@ -245,7 +245,19 @@ class AnymalTerrainTask(RLTask):
         self.init_done = True
 
     # ------------------------------------------------------------------ C-ABI argument blocks
+    _PARAM_SCALARS = ("lin_vel_scale", "ang_vel_scale", "dof_pos_scale", "dof_vel_scale", "height_meas_scale", "action_scale", "Kp", "Kd",
+                      "max_episode_length_s", "max_episode_length", "curriculum", "init_done", "add_noise")
+
     def _params(self) -> _lib.AnymalParams:
+        """Cached (RLTask._block): rebuilt when a public scalar, the reward scales, the command ranges, the noise scales, the
+        terrain or the height map changed."""
+        d = self.__dict__
+        scal = [d.get(k) for k in self._PARAM_SCALARS]
+        scal += [tuple(self.rew_scales.values()), tuple(self.command_x_range), tuple(self.command_y_range), tuple(self.command_yaw_range),
+                 tuple(d.get("_noise_scales", ())), tuple(d.get("_base_init_host", ())), tuple(self._default_dof_host)]
+        return self._block("params", (self.terrain, self.height_samples), scal, self._build_params)
+
+    def _build_params(self) -> _lib.AnymalParams:
         p = _lib.AnymalParams()
         p.lin_vel_scale, p.ang_vel_scale = self.lin_vel_scale, self.ang_vel_scale
         p.dof_pos_scale, p.dof_vel_scale = self.dof_pos_scale, self.dof_vel_scale
@@ -275,10 +287,16 @@ class AnymalTerrainTask(RLTask):
         return p
 
     def _state(self) -> _lib.AnymalState:
-        n = self._num_envs
-        rq = _lib.require_device_tensor
         knee = self._anymals._knees.get_net_contact_forces(clone=False)
         base = self._anymals._base.get_net_contact_forces(clone=False)
+        hmin = self._height_min_table() if self.use_height_min else None
+        live = (self.base_pos, self.base_quat, self.base_velocities, self.dof_pos, self.dof_vel, knee, base, self.height_samples,
+                self.terrain_origins, hmin)
+        return self._block("state", live, (), lambda: self._build_state(knee, base, hmin))
+
+    def _build_state(self, knee, base, hmin) -> _lib.AnymalState:
+        n = self._num_envs
+        rq = _lib.require_device_tensor
         rq(self.base_pos, torch.float32, (n, 3), "base_pos")
         rq(self.base_quat, torch.float32, (n, 4), "base_quat")
         rq(self.base_velocities, torch.float32, (n, 6), "base_velocities")
@@ -293,9 +311,8 @@ class AnymalTerrainTask(RLTask):
         s.dof_pos, s.dof_vel = self.dof_pos.data_ptr(), self.dof_vel.data_ptr()
         s.knee_contact, s.base_contact = knee.data_ptr(), base.data_ptr()
         s.height_samples, s.terrain_origins = self.height_samples.data_ptr(), self.terrain_origins.data_ptr()
-        if self.use_height_min:
-            s.height_min = self._height_min_table().data_ptr()
-        self._live_state = (knee, base)
+        if hmin is not None:
+            s.height_min = hmin.data_ptr()
         return s
 
     # get_heights keeps min(h[px, py], h[px + 1, py + 1]) (:598-600): tabulated once per map, one gather per scan point
@@ -314,6 +331,13 @@ class AnymalTerrainTask(RLTask):
         return self._height_min
 
     def _buffers(self) -> _lib.AnymalBuffers:
+        ts = (self.obs_buf, self.rew_buf, self._reset_bool, self.has_fallen, self.timeout_buf, self.progress_buf, self.commands,
+              self.actions, self.last_actions, self.last_dof_vel, self.torques, self.feet_air_time, self._episode_sums,
+              self.terrain_levels, self.terrain_types, self.env_origins, self._extras_dev, self._reset_workspace,
+              self._reduce_workspace, self._tile_counts_u8)
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.AnymalBuffers:
         n = self._num_envs
         rq = _lib.require_device_tensor
         rq(self.obs_buf, torch.float32, (n, 188), "obs_buf")
@@ -342,9 +366,17 @@ class AnymalTerrainTask(RLTask):
         return b
 
     def _reset_io(self, draws=None, noise_u=None, mask=None, push=False) -> _lib.AnymalResetIO:
+        pushing = bool(push and self.device_push and self.push_interval > 0)
+        ts = (*(draws or ()), noise_u, mask, self.base_velocities if pushing else None, self._push_count, *self._reset_out.values(),
+              self._step_dev if self._capturing else None)
+        scal = (self._rand_seed, pushing, int(self.push_interval), int(self._common_offset))
+        r = self._block("reset_io", ts, scal, lambda: self._build_reset_io(draws, noise_u, mask, push))
+        r.step = self._step_count  # the one field that changes from step to step
+        return r
+
+    def _build_reset_io(self, draws, noise_u, mask, push) -> _lib.AnymalResetIO:
         r = _lib.AnymalResetIO()
         if draws is not None:
-            self._live_draws = draws
             r.u_dof_offset, r.u_dof_vel, r.u_xy, r.u_cmd = (d.data_ptr() for d in draws)
         if noise_u is not None:
             _lib.require_device_tensor(noise_u, torch.float32, (self._num_envs, 188), "noise_u")
@@ -352,13 +384,12 @@ class AnymalTerrainTask(RLTask):
         if mask is not None:
             r.reset_mask = mask.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
-        r.step = self._step_count
         r.step_ptr = self._graph_step_ptr()  # graph capture: the step counter lives on the device
         if push and self.device_push and self.push_interval > 0:
             _lib.require_device_tensor(self.base_velocities, torch.float32, (self._num_envs, 6), "base_velocities")
             r.push_velocities, r.push_count = self.base_velocities.data_ptr(), self._push_count.data_ptr()
             r.push_interval = int(self.push_interval)
-            r.push_offset = int(self.common_step_counter) - int(self._step_count)
+            r.push_offset = int(self._common_offset)  # common_step_counter - _step_count
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.base_pos_out, r.base_quat_out, r.base_vel_out = o["base_pos"].data_ptr(), o["base_quat"].data_ptr(), o["base_vel"].data_ptr()
@@ -405,7 +436,24 @@ class AnymalTerrainTask(RLTask):
         self._bind_extras()
 
     def update_terrain_level(self, env_ids):
-        raise _lib.OigeError("update_terrain_level runs inside oige_anymal_post_physics / oige_anymal_reset_idx (:369-380)")
+        """:369-380 on its own (inside a step it is part of the reset: oige_anymal_post_physics / oige_anymal_reset_idx)."""
+        if not self.init_done or not self.curriculum:  # :370-372
+            return
+        env_ids = env_ids.to(device=self.device, dtype=torch.int64).contiguous()
+        root_pos, _ = self._anymals.get_world_poses(clone=False)
+        n = self._num_envs
+        rq = _lib.require_device_tensor
+        rq(root_pos, torch.float32, (n, 3), "root_pos")
+        rq(self.commands, torch.float32, (n, 4), "commands")
+        rq(self.terrain_levels, torch.int64, (n,), "terrain_levels")
+        rq(self.terrain_types, torch.int64, (n,), "terrain_types")
+        rq(self.env_origins, torch.float32, (n, 3), "env_origins")
+        p = self._params()
+        rc = _lib.load().oige_anymal_update_terrain_level(
+            C.byref(p), root_pos.data_ptr(), self.terrain_origins.data_ptr(), self.commands.data_ptr(), self.terrain_levels.data_ptr(),
+            self.terrain_types.data_ptr(), self.env_origins.data_ptr(), env_ids.data_ptr(), int(env_ids.numel()), n,
+            _lib.current_stream(self.obs_buf.device))
+        _lib.check(rc, "oige_anymal_update_terrain_level")
 
     def refresh_dof_state_tensors(self):
         self.dof_pos = self._anymals.get_joint_positions(clone=False)
@@ -444,6 +492,35 @@ class AnymalTerrainTask(RLTask):
         if not cloned:  # decimation 0 or the world stopped inside the loop: no launch took the copy
             self.actions.copy_(actions)
 
+    # the reference keeps the body-frame quantities of :422-424 as attributes; the fused step leaves them in registers unless
+    # asked to write them out (12 extra bytes x 3 per env and step)
+    materialize_frame = False
+
+    def _frame(self) -> _lib.AnymalFrame:
+        if getattr(self, "base_lin_vel", None) is None:
+            f = dict(dtype=torch.float, device=self.device)
+            self.base_lin_vel = torch.zeros((self._num_envs, 3), **f)
+            self.base_ang_vel = torch.zeros((self._num_envs, 3), **f)
+            self.projected_gravity = torch.zeros((self._num_envs, 3), **f)
+        ts = (self.base_lin_vel, self.base_ang_vel, self.projected_gravity)
+        return self._block("frame", ts, (), self._build_frame)
+
+    def _build_frame(self) -> _lib.AnymalFrame:
+        x = _lib.AnymalFrame()
+        for name in ("base_lin_vel", "base_ang_vel", "projected_gravity"):
+            t = getattr(self, name)
+            _lib.require_device_tensor(t, torch.float32, (self._num_envs, 3), name)
+            setattr(x, name, t.data_ptr())
+        return x
+
+    def _stages(self, stages: int, noise_u=None, push: bool = False):
+        """One ``oige_anymal_post_physics_stages`` call; returns the reset_io block it used."""
+        p, s, b, r = self._params(), self._state(), self._buffers(), self._reset_io(noise_u=noise_u, push=push)
+        rc = _lib.load().oige_anymal_post_physics_stages(C.byref(p), C.byref(s), C.byref(b), C.byref(r), C.byref(self._frame()),
+                                                         self._num_envs, stages, _lib.current_stream(self.obs_buf.device))
+        _lib.check(rc, "oige_anymal_post_physics_stages")
+        return r
+
     def post_physics_step(self, noise_u=None):
         if not self.world.is_playing():
             self.progress_buf[:] += 1
@@ -453,10 +530,15 @@ class AnymalTerrainTask(RLTask):
         self._advance_step_counter()  # common_step_counter += 1 (:418): it is _step_count + a constant, see the property
         if not self.device_push and self.common_step_counter % self.push_interval == 0:
             self.push_robots()
-        p, s, b, r = self._params(), self._state(), self._buffers(), self._reset_io(noise_u=noise_u, push=True)
-        rc = _lib.load().oige_anymal_post_physics(C.byref(p), C.byref(s), C.byref(b), C.byref(r), self._num_envs,
-                                                  _lib.current_stream(self.obs_buf.device))
-        _lib.check(rc, "oige_anymal_post_physics")
+        if not self.fused:
+            return self._post_physics_step_by_stages(noise_u)
+        if self.materialize_frame:
+            r = self._stages(_lib.ANYMAL_STAGE_ALL, noise_u=noise_u, push=True)
+        else:
+            p, s, b, r = self._params(), self._state(), self._buffers(), self._reset_io(noise_u=noise_u, push=True)
+            rc = _lib.load().oige_anymal_post_physics(C.byref(p), C.byref(s), C.byref(b), C.byref(r), self._num_envs,
+                                                      _lib.current_stream(self.obs_buf.device))
+            _lib.check(rc, "oige_anymal_post_physics")
         if r.push_velocities:  # :450 with a device-side count: N on a push step, 0 otherwise
             self._anymals.set_velocities(self.base_velocities, indices=self._all_indices, count=self._push_count)
         self.reset_buf = self._reset_bool  # bool, as the reference rebinds it (:465)
@@ -464,19 +546,50 @@ class AnymalTerrainTask(RLTask):
         self._bind_extras()
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
+    def _post_physics_step_by_stages(self, noise_u=None):
+        """``task.fused = False``: the reference's own sequence (:410-442), one method per stage, host-visible id list, torch
+        draws for the reset and the noise -- what a subclass that overrides a stage gets."""
+        self._stages(_lib.ANYMAL_STAGE_PROGRESS)                                  # :410
+        self.compute_body_frame()                                                 # :421-427
+        self.check_termination()                                                  # :429
+        self.calculate_metrics()                                                  # :431
+        env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()                # :433
+        if len(env_ids) > 0:
+            self.reset_idx(env_ids)                                               # :435
+        self.get_observations()                                                   # :437
+        if self.add_noise:                                                        # :438-439
+            u = noise_u if noise_u is not None else torch.rand_like(self.obs_buf)
+            self.obs_buf += (2 * u - 1) * self.noise_scale_vec
+        self.last_actions[:] = self.actions[:]                                    # :441
+        self.last_dof_vel[:] = self.dof_vel[:]                                    # :442
+        return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
+
     def push_robots(self):
         self.base_velocities[:, 0:2] = 2.0 * torch.rand(self.num_envs, 2, device=self.device) + (-1.0)  # lin vel x/y
         self._anymals.set_velocities(self.base_velocities)
 
-    # the reference's post_physics_step is the only caller of these (:429-437); here they are one kernel
+    # ---- the stages of post_physics_step as methods of their own, as in the reference (each ONE C-ABI call on the same
+    # kernels as the fused step, which stays bit-identical to their sequence: tests/test_anymal_gpu.py)
+    def compute_body_frame(self):
+        """:421-427 (inline in the reference's post_physics_step): ``base_lin_vel``, ``base_ang_vel``, ``projected_gravity``
+        and the heading command ``commands[:, 2]``."""
+        self._stages(_lib.ANYMAL_STAGE_FRAME)
+
     def check_termination(self):
-        raise _lib.OigeError("check_termination is fused into post_physics_step (oige_anymal_post_physics)")
+        """:452-466: ``timeout_buf``, ``has_fallen``, ``reset_buf`` (rebound to the bool tensor, as :465 does)."""
+        self._stages(_lib.ANYMAL_STAGE_TERMINATION)
+        self.reset_buf = self._reset_bool
 
     def calculate_metrics(self):
-        raise _lib.OigeError("calculate_metrics is fused into post_physics_step (oige_anymal_post_physics)")
+        """:468-533: ``rew_buf`` and the ten episode sums, from the attributes ``compute_body_frame`` left."""
+        self._stages(_lib.ANYMAL_STAGE_METRICS)
 
     def get_observations(self):
-        raise _lib.OigeError("get_observations is fused into post_physics_step (oige_anymal_post_physics)")
+        """:535-552: ``obs_buf`` (no noise: that is :438-439) with the height scan of the views' current state."""
+        self.refresh_dof_state_tensors()
+        self.refresh_body_state_tensors()
+        self._stages(_lib.ANYMAL_STAGE_OBS)
+        return {self._anymals.name: {"obs_buf": self.obs_buf}}
 
     def is_done(self):
         pass
