@@ -426,6 +426,62 @@ class QuadcopterBench:
         return step
 
 
+class CartpoleBench:
+    """C1 (BASELINE.json configs[0], the plumbing config): Cartpole obs(4) + reward + done + reset, 4096 envs, cartpole.py:91-164.
+    At this size the step is two launches of a few microseconds each: the line measures launch + marshalling cost, not HBM."""
+
+    def __init__(self, name, n, dev, seed, reset_frac=None):
+        from omniisaacgymenvs_amd.utils.task_util import make_task
+        from omniisaacgymenvs_amd.sim import workloads
+
+        self.env, self.task = make_task("Cartpole", n, device=dev, seed=seed)
+        t = self.task
+        st = workloads.cartpole_state(n, device=dev, seed=seed)
+        if reset_frac is not None:  # everyone upright and centred except `reset_frac` of the carts beyond resetDist
+            bad = _pick(n, reset_frac, dev, seed)
+            st["dof_pos"] = (torch.rand(n, 2, device=dev) * 0.4 - 0.2).contiguous()
+            st["dof_pos"][bad, 0] = 3.2
+            st["progress"] = torch.randint(0, 400, (n,), device=dev)
+        t._cartpoles.joint_positions.copy_(st["dof_pos"])
+        t._cartpoles.joint_velocities.copy_(st["dof_vel"])
+        t.progress_buf.copy_(st["progress"])
+        t.reset_buf.zero_()
+        t._cartpoles.apply_resets = False
+        self.actions = st["actions"]
+        self.post_bytes = 60  # SURVEY.md 8d: R dof_pos 8 + dof_vel 8 + progress 8; W obs 16 + rew 4 + reset 8 + progress 8
+        # pre: R actions 4 + reset flag 8, W forces 8; per reset env W dof_pos / dof_vel rows 16, id 8, reset + progress 16
+        self.pre_bytes = lambda resets: 20 * n + 40 * resets
+        self.kernel = "cartpole_post_kernel"
+        self.workload = f"Cartpole obs(4)+reward+reset fused, {n} envs per GPU, synthetic DOF state"
+        self.extra_cfg = {"num_dof": 2}
+
+    def pre(self):
+        self.task.pre_physics_step(self.actions)
+
+    def post(self):
+        self.task.post_physics_step()
+
+    def resets(self):
+        return int(self.task._reset_out["count"].item())
+
+    @staticmethod
+    def cpu_baseline(name, n, budget_s):
+        from omniisaacgymenvs_amd.sim import workloads
+        from oracle import cartpole_oracle as co
+
+        spec = co.CartpoleSpec()
+        st = workloads.cartpole_state(n, device="cpu", seed=1234)
+        obs, rew = torch.zeros(n, 4), torch.zeros(n)
+        reset, progress = torch.zeros(n, dtype=torch.long), st["progress"].clone()
+        draw = lambda ids: torch.rand(4, len(ids))
+
+        def step():
+            co.pre_physics(spec, st["actions"], reset, progress, draw=draw)
+            co.post_physics(spec, st["dof_pos"], st["dof_vel"], obs, rew, reset, progress)
+
+        return step
+
+
 class BallBalanceBench:
     """BallBalance obs(24) + reward + sticky done, position-target integration."""
 
@@ -767,8 +823,8 @@ class AnymalFlatBench:
         return step
 
 
-ADAPTERS = {"TomoDJnewhandCabinet": NewhandCabinetBench, "TomoDJnewhandTendonCabinet": NewhandCabinetBench, "TomoSPCnewhandCabinet": NewhandCabinetBench, "TomoDJCabinet": FrankaCabinetBench, "TomoSPCCabinet": FrankaCabinetBench, "FrankaCabinet": FrankaCabinetBench, "Crazyflie": CrazyflieBench, "Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
-DEFAULT_ENVS = {"TomoDJnewhandCabinet": 1 << 19, "TomoDJnewhandTendonCabinet": 1 << 19, "TomoSPCnewhandCabinet": 1 << 19, "TomoDJCabinet": 1 << 20, "TomoSPCCabinet": 1 << 20, "FrankaCabinet": 1 << 20, "Crazyflie": 1 << 20, "Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
+ADAPTERS = {"Cartpole": CartpoleBench, "TomoDJnewhandCabinet": NewhandCabinetBench, "TomoDJnewhandTendonCabinet": NewhandCabinetBench, "TomoSPCnewhandCabinet": NewhandCabinetBench, "TomoDJCabinet": FrankaCabinetBench, "TomoSPCCabinet": FrankaCabinetBench, "FrankaCabinet": FrankaCabinetBench, "Crazyflie": CrazyflieBench, "Ingenuity": IngenuityBench, "BallBalance": BallBalanceBench, "Quadcopter": QuadcopterBench, "AllegroHand": AllegroHandBench, "Anymal": AnymalFlatBench, "Ant": LocomotionBench, "Humanoid": LocomotionBench, "ShadowHand": HandBench, "AnymalTerrain": AnymalBench}
+DEFAULT_ENVS = {"Cartpole": 4096, "TomoDJnewhandCabinet": 1 << 19, "TomoDJnewhandTendonCabinet": 1 << 19, "TomoSPCnewhandCabinet": 1 << 19, "TomoDJCabinet": 1 << 20, "TomoSPCCabinet": 1 << 20, "FrankaCabinet": 1 << 20, "Crazyflie": 1 << 20, "Ingenuity": 1 << 20, "BallBalance": 1 << 20, "Quadcopter": 1 << 20, "AllegroHand": 1 << 20, "Anymal": 1 << 20, "Ant": 1 << 20, "Humanoid": 1 << 19, "ShadowHand": 1 << 20, "AnymalTerrain": 1 << 18}
 
 
 def measured_copy_gbs(dev: str, footprint_bytes: int) -> dict:
@@ -951,7 +1007,7 @@ def main() -> None:
     ap.add_argument("--reset-frac", type=float, default=None,
                     help="second workload: only this fraction of the envs terminates per step (0.001 = the reference's steady "
                          "state, about N/1000 resets per step, SURVEY.md a8); default: the r01 workload, 13-25 %% per step")
-    ap.add_argument("--event-every", type=int, default=int(os.environ.get("OIGE_BENCH_EVENT_EVERY", "4")),
+    ap.add_argument("--event-every", type=int, default=int(os.environ.get("OIGE_BENCH_EVENT_EVERY", "5")),
                     help="HIP-event brackets around pre / post on every k-th timed step (1: every step, as r01 / r02 did)")
     ap.add_argument("--stats-every", type=int, default=0,
                     help="N > 1: the episode-statistics all-reduce on every k-th step (this rank's sums are kept every step).  "
@@ -1121,12 +1177,14 @@ def main() -> None:
     if not dry and not args.graph and not args.no_graph_leg:
         graph_ms, graph_note = graph_leg(bench, args.steps, dist)
 
-    traffic = None
+    traffic = traffic_source = None
     if args.traffic_json and os.path.exists(args.traffic_json) and not dry:
         with open(args.traffic_json) as f:
             rec = json.load(f).get(args.task)
         if rec:  # measured at rec["envs"] envs per launch; the kernels stream, so bytes scale with the env count
             traffic = rec["hbm_bytes_per_launch"] * n / rec["envs"]
+            traffic_source = (f"{os.path.relpath(args.traffic_json, ROOT)}: rocprofv3 --pmc 2 x FETCH_SIZE + WRITE_SIZE of {rec.get('kernel', 'the post kernel')}"
+                              f" at {rec['envs']} envs ({rec.get('captured', 'profiles/run_profiles.sh')}), scaled to this run's env count; not measured in this run")
 
     if rank == 0:
         cfg = {"workload": bench.workload, "envs_per_gpu": n, "resets_per_step": bench.resets(),
@@ -1168,7 +1226,7 @@ def main() -> None:
             achieved = bench.post_bytes * n / (post_ms * 1e-3) / 1e9
             out["roofline"] = {
                 "bound": "hbm", "kernel": bench.kernel + (" (+ pre_physics: whole replayed graph timed)" if args.graph else ""), "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_env": bench.post_bytes, "avg_kernel_ms": post_ms,
                 "pre_physics_ms": pre_ms, "gpu_ms_per_step": gpu_span_ms,
                 "event_brackets": f"every {max(1, args.event_every)}. timed step ({len(timed)} of {args.steps})",

@@ -67,7 +67,11 @@ int oige_compact_i64(const int64_t* flags, int64_t n, int32_t* workspace, int64_
  * the workspace is a 320 KiB array inside the library's device image (every GPU the library runs on holds its own copy
  * until the process ends).  The call allocates and frees nothing.  n <= oige_compact_static_max_envs() (4 194 304);
  * larger n is rejected with OIGE_EINVAL.  All calls on one GPU share that GPU's array: calls that overlap on one GPU
- * (two streams, two threads) race -- serialise them, or use oige_compact_i64 with separate workspaces.           */
+ * (two streams, two threads) race -- serialise them, or use oige_compact_i64 with separate workspaces.
+ * `stream` (when not NULL) must belong to the CURRENT device -- the scratch address is per device and is looked up for the
+ * current one; a stream of another GPU is rejected with OIGE_EINVAL.  The first call on a device performs that look-up
+ * (hipGetSymbolAddress): make it outside stream capture (any call will do, n = 0 included); later calls are capturable
+ * and replayable (tests/test_zz_no_alloc.py).                                                                       */
 int64_t oige_compact_static_max_envs(void);
 int oige_compact_i64_static(const int64_t* flags, int64_t n, int64_t* ids_out, int64_t* count_out, oige_stream_t stream);
 
@@ -184,7 +188,13 @@ typedef struct oige_locomotion_reset_io {
 #define OIGE_PRE_COUNTS_VALID 2u  /* the workspaces' tile counts already match the flag buffers (skip the recount): true right
                                    * after a *_post_physics call with OIGE_STAGE_DONE on the same buffers and nothing written
                                    * to them since.  Ingenuity / Crazyflie: the DONE stage also leaves target_workspace's
-                                   * counts (reset | progress % 500 == 0), so progress_buf must be untouched as well. */
+                                   * counts (reset | progress % 500 == 0), so progress_buf must be untouched as well.
+                                   * "The same buffers" includes the workspaces themselves: that post call must have been given
+                                   * the SAME non-NULL reset_workspace (and target_workspace) and the SAME tile_counts_u8
+                                   * table(s) this pre call gets -- the post kernels leave counts only in the tables they
+                                   * are handed (a NULL there skips them), and a table first supplied to the pre call holds
+                                   * whatever it held before: stale ranks, wrong ids, no diagnostic.  When in doubt leave the
+                                   * flag off: the recount is one 5 us launch.                                          */
 #define OIGE_PRE_OFFSETS_VALID 4u /* in-hand tasks: the group offsets are valid too (oige_hand_post_physics[_dr] with
                                    * OIGE_STAGE_METRICS scans both workspaces in its last launch): implies COUNTS_VALID,
                                    * same condition; pre_physics then starts at its kernel */

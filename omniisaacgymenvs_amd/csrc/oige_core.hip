@@ -106,11 +106,18 @@ static __device__ __align__(256) int32_t scratch[STATIC_SCRATCH_INTS];
 constexpr int STATIC_MAX_DEVICES = 64;
 static std::atomic<int32_t*> scratch_ptr[STATIC_MAX_DEVICES];  // per device: each GPU has its own copy at its own address
 
-// The address of `scratch` on the CURRENT device (looked up once per device, with that device current).
-static int static_scratch(int32_t** out) {
+// The address of `scratch` on the CURRENT device (looked up once per device, with that device current).  `stream` must
+// belong to that device: a stream of another GPU would run the kernels there, writing through THIS device's address.
+static int static_scratch(int32_t** out, hipStream_t stream) {
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= STATIC_MAX_DEVICES)
     return fail(OIGE_ELAUNCH, "compact_static: no current HIP device (or device index >= %d)", STATIC_MAX_DEVICES);
+  if (stream != nullptr) {
+    int sdev = -1;
+    if (hipStreamGetDevice(stream, &sdev) == hipSuccess && sdev != dev)
+      return fail(OIGE_EINVAL, "compact_static: the stream belongs to device %d but device %d is current (each GPU has its own scratch: "
+                  "make the stream's device current)", sdev, dev);
+  }
   int32_t* p = scratch_ptr[dev].load(std::memory_order_acquire);
   if (!p) {
     void* sym = nullptr;
@@ -183,7 +190,7 @@ int oige_compact_i64_static(const int64_t* flags, int64_t n, int64_t* ids_out, i
                "oige_compact_i64 with a caller workspace", (long long)n, (long long)STATIC_MAX_ENVS);
   static_assert(STATIC_SCRATCH_INTS >= (STATIC_MAX_ENVS / GROUP) * GROUP_TILES + STATIC_MAX_ENVS / GROUP + 1, "scratch too small");
   int32_t* ws = nullptr;
-  int rc = static_scratch(&ws);
+  int rc = static_scratch(&ws, (hipStream_t)stream);
   if (rc) return rc;
   // Nothing in the scratch has to start at zero: count writes every tile count of the n envs' groups (padding tiles
   // included), scan every group offset and the total, and emit reads only those -- the last call's contents are dead.

@@ -121,13 +121,25 @@ OIGE_DEV void get_euler_xyz(const q4 q, float& roll, float& pitch, float& yaw) {
   const float siny_cosp = 2.0f * (q.w * q.z + q.x * q.y);
   const float cosy_cosp = ((q.w * q.w + q.x * q.x) - q.y * q.y) - q.z * q.z;
   const float y = atan2f(siny_cosp, cosy_cosp);
-  roll = remainder_pos(r, OIGE_TWO_PI_F);
-  pitch = remainder_pos(p, OIGE_TWO_PI_F);
-  yaw = remainder_pos(y, OIGE_TWO_PI_F);
+  // `% 2 pi` of an atan2 / asin result: |m| <= pi < 2 pi, so fmod(m, 2 pi) is m itself, bit for bit, and remainder_pos
+  // reduces to its shift of the negatives (the library fmodf was ~30 instructions per angle for the identity)
+  roll = r < 0.0f ? r + OIGE_TWO_PI_F : r;
+  pitch = p < 0.0f ? p + OIGE_TWO_PI_F : p;
+  yaw = y < 0.0f ? y + OIGE_TWO_PI_F : y;
 }
 
-// jit normalize_angle (locomotion.py:220-221)
-OIGE_DEV float normalize_angle(const float x) { return atan2f(sinf(x), cosf(x)); }
+// jit normalize_angle (locomotion.py:220-221): atan2(sin x, cos x), i.e. x reduced to (-pi, pi].  Evaluated as that
+// reduction, in double (x - 2 pi rint(x / 2 pi): five instructions), instead of through sinf, cosf and atan2f (~100 each
+// time, three times per env: a third of the locomotion post kernel's per-env arithmetic).  Not the reference's operation
+// order, on purpose: the three angles feed no threshold (reward and done read obs[0], obs[10], obs[11] only), the result
+// is the exact value rounded once -- within 1 ulp (2.4e-7) of torch's atan2(sin, cos) over [-3 pi - 1, 2 pi + 1] and on every
+// float within 40 ulps of a multiple of pi, the side of the +-pi seam included (x is a float, never exactly an odd multiple
+// of pi, so sin x and the reduction agree on the sign; oracle/div_check-style sweep in tests/test_helpers_known_answers.py).
+OIGE_DEV float normalize_angle(const float x) {
+  const double xd = (double)x;
+  const double k = __builtin_rint(xd * 0.15915494309189535);  // 1 / (2 pi)
+  return (float)__builtin_fma(-k, 6.283185307179586, xd);
+}
 
 // unscale / scale / tensor_clamp (locomotion.py:263,138; in_hand_manipulation.py:343-361)
 OIGE_DEV float unscale(const float x, const float lo, const float hi) { return ((2.0f * x - hi) - lo) / (hi - lo); }

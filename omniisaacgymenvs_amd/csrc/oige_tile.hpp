@@ -87,10 +87,11 @@ __device__ __forceinline__ void scatter_chunk(const Chunk<K, NT>& c, float* __re
       *reinterpret_cast<float4*>(tile + env * ROW + COL0 + col) = t;
     } else {
       const float tv[4] = {t.x, t.y, t.z, t.w};
+      int row = e / K, col = e - row * K;  // one division per float4, then a cursor (Humanoid: K = 21, 1200 float4 per tile)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const int ee = e + k;
-        tile[(ee / K) * ROW + COL0 + (ee % K)] = tv[k];
+        tile[row * ROW + COL0 + col] = tv[k];
+        if (++col == K) { col = 0; ++row; }
       }
     }
   }

@@ -82,3 +82,34 @@ def test_fma_division_by_constant_equals_ieee_division(tmp_path):
     out = subprocess.run([exe, "2000000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "mismatches 0" in out.stdout
+
+
+def test_normalize_angle_as_a_reduction_matches_atan2_of_sin_cos():
+    """csrc/oige_math.hpp evaluates the jit normalize_angle (locomotion.py:220-221: atan2(sin x, cos x)) as the reduction of x
+    to (-pi, pi] in double -- five instructions instead of three library calls.  This replays that arithmetic with numpy
+    against torch's own atan2(sin, cos): within 1 ulp everywhere the locomotion kernels can reach ([-3 pi - 1, 2 pi + 1]:
+    yaw, roll in [0, 2 pi), angle_to_target = atan2(..) - yaw), and on the same side of the +-pi seam for every float within 40
+    ulps of a multiple of pi.  (The GPU side of the same statement: tests/test_locomotion_gpu.py compares obs columns 7:10.)"""
+    import math
+
+    import numpy as np
+
+    g = torch.Generator().manual_seed(0)
+    x = (torch.rand(2_000_000, generator=g) * (5 * math.pi + 2) - (3 * math.pi + 1)).float()
+    seams = []
+    for m in range(-4, 5):
+        v = np.float32(m * math.pi)
+        for _ in range(40):
+            v = np.nextafter(v, np.float32(-100))
+        for _ in range(80):
+            seams.append(float(v))
+            v = np.nextafter(v, np.float32(100))
+    x = torch.cat([x, torch.tensor(seams, dtype=torch.float32)])
+    ref = torch.atan2(torch.sin(x), torch.cos(x))
+    xd = x.double().numpy()
+    k = np.rint(xd * 0.15915494309189535)
+    mine = torch.from_numpy((xd - k * 6.283185307179586).astype(np.float32))  # (numpy has no fma: the product is exact enough in double)
+    d = (ref - mine).abs()
+    assert float(d.max()) <= 2.4e-7, float(d.max())
+    assert int(((ref > 0) != (mine > 0)).sum()) == 0  # the seam: same sign on every float around an odd multiple of pi
+    assert bool((d <= 1e-6 + 1e-5 * ref.abs()).all())

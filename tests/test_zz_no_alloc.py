@@ -66,3 +66,30 @@ def test_static_compaction_rejects_sizes_beyond_its_scratch():
     _lib.compact_static(big, ids, cnt)
     torch.cuda.synchronize()
     assert int(cnt) == 2 and ids[:2].tolist() == [12345, cap - 1]
+
+
+def test_static_compaction_is_capturable_after_one_warm_call():
+    """the use case the header names is code under graph capture.  The first call on a device looks the scratch
+    address up (hipGetSymbolAddress) and so happens outside the window; the call inside it is captured and replayed on new
+    flags."""
+    dev = torch.device("cuda:0")
+    n = 5000
+    g = torch.Generator(device="cpu").manual_seed(9)
+    flags = (torch.rand(n, generator=g) < 0.2).long().to(dev)
+    ids = torch.full((n,), -7, dtype=torch.int64, device=dev)
+    cnt = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    _lib.compact_static(flags, ids, cnt)  # warm call: per-device look-up, code objects
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        _lib.compact_static(flags, ids, cnt)
+    for p in (0.7, 0.0, 0.05):
+        flags.copy_((torch.rand(n, generator=g) < p).long())
+        ids.fill_(-7)
+        graph.replay()
+        torch.cuda.synchronize()
+        want = flags.nonzero().squeeze(-1)
+        assert int(cnt) == want.numel()
+        assert torch.equal(ids[: want.numel()], want) and bool((ids[want.numel():] == -7).all())
