@@ -1106,9 +1106,16 @@ def main() -> None:
     # 150-200 us more on the host (profiles/tools/dbg_first_step.py): 7 % of a 20-step run when it was the first timed step
     t = bench.task
     od.all_reduce_stats(od.local_stats(t.rew_buf, t.reset_buf, t.progress_buf, getattr(t, "successes", None)))
-    for _ in range(args.warmup):
+    # What a bracket adds to the kernel it brackets: an ADJACENT pair of records (nothing between them) behind a step's kernels,
+    # during the warm-up.  Reported next to the raw brackets (roofline.event_overhead_ms, *_net); rocprofv3's kernel
+    # durations (profiles/r03/stats) are the check.
+    cal = [] if dry else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.warmup)]
+    for i in range(args.warmup):
         bench.pre()
         bench.post()
+        if cal:
+            cal[i][0].record()
+            cal[i][1].record()
         after()
         exchange()
     if reducer is not None:  # one whole collective as warm-up, then the timed region's statistics start from zero
@@ -1162,6 +1169,10 @@ def main() -> None:
                  if not any(isinstance(e, _NoEvent) for e in (es, e0, e1))]
         post_ms = sum(a.elapsed_time(b) for _, a, b in timed) / max(1, len(timed))
         pre_ms = sum(es.elapsed_time(e0) for es, e0, _ in timed) / max(1, len(timed))
+    event_overhead_ms = None
+    if not dry and cal:
+        gaps = sorted(a.elapsed_time(b) for a, b in cal)
+        event_overhead_ms = gaps[len(gaps) // 2]
     if not dry:
         gpu_span_ms = ev_start[0].elapsed_time(ev_pairs[-1][1]) / len(ev_pairs)  # first pre launch -> last post end, per step
         if os.environ.get("OIGE_BENCH_DUMP_STEPS") and not args.graph:  # per-step (pre, post, gap to the next step) in us, to stderr
@@ -1230,6 +1241,7 @@ def main() -> None:
                 "algorithmic_bytes_per_env": bench.post_bytes, "avg_kernel_ms": post_ms,
                 "pre_physics_ms": pre_ms, "gpu_ms_per_step": gpu_span_ms,
                 "event_brackets": f"every {max(1, args.event_every)}. timed step ({len(timed)} of {args.steps})",
+                "event_overhead_ms": event_overhead_ms,
                 "measured_copy_gbs": copy_gbs,
                 "frac_of_measured_copy_12_streams": achieved / copy_gbs["streams_12"],
             }
@@ -1240,6 +1252,12 @@ def main() -> None:
                 step_gbs = (pb + bench.post_bytes * n) / (gpu_span_ms * 1e-3) / 1e9
                 out["roofline"]["pre"] = {"what": "everything the step launches before the post kernel (compaction scan, resets, action scaling)",
                                           "algorithmic_bytes": pb, "ms": pre_ms, "achieved": pre_gbs, "frac": pre_gbs / HBM_PEAK_GBS}
+                if event_overhead_ms is not None and not args.graph:
+                    net_post, net_pre = max(post_ms - event_overhead_ms, 1e-9), max(pre_ms - event_overhead_ms, 1e-9)
+                    out["roofline"]["net_of_event_overhead"] = {
+                        "what": "the brackets minus one adjacent-record gap (event_overhead_ms); compare with rocprofv3 kernel durations",
+                        "avg_kernel_ms": net_post, "frac": bench.post_bytes * n / (net_post * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "pre_physics_ms": net_pre, "pre_frac": pb / (net_pre * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 out["roofline"]["step"] = {"what": "pre + post algorithmic bytes over gpu_ms_per_step (first launch to last kernel end)",
                                            "algorithmic_bytes": pb + bench.post_bytes * n, "ms": gpu_span_ms, "achieved": step_gbs,
                                            "frac": step_gbs / HBM_PEAK_GBS}
