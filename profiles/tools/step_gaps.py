@@ -2,16 +2,20 @@
 """Per-step kernel durations and the idle gaps between consecutive kernels, from a rocprofv3 --kernel-trace CSV.
 
     rocprofv3 --kernel-trace --output-format csv -d /tmp/kt -o k -- python3 bench.py --task Ant --steps 50 --no-cpu-baseline --no-graph-leg
-    python profiles/tools/step_gaps.py /tmp/kt/**/k_kernel_trace.csv [last-N-launches]
+    python profiles/tools/step_gaps.py /tmp/kt/**/k_kernel_trace.csv [last-N-launches] [name-filter]
 
-Prints, over the last N launches (default 200: the timed steps, past warm-up and calibration), each oige kernel's mean
-duration and the mean gap between a kernel's end and the next kernel's start, keyed by the pair of kernels."""
+Prints, over the window that ends at the LAST launch whose name contains the filter (default "oige::": the library's own
+kernels, so the bench's bookkeeping behind the timed loop stays out) and holds N launches (default 200: timed steps, past
+warm-up and calibration), each kernel's mean duration and the mean gap between a kernel's end and the next kernel's start,
+keyed by the pair of kernels."""
 import collections, csv, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-rows = rows[-n:]
+flt = sys.argv[3] if len(sys.argv) > 3 else "oige::"
+last = max((i for i, r in enumerate(rows) if flt in r["Kernel_Name"]), default=len(rows) - 1)
+rows = rows[max(0, last + 1 - n):last + 1]
 
 
 def short(name):
