@@ -203,9 +203,10 @@ __device__ __forceinline__ void anymal_flat_reset_head(const AnymalFlatPre& a, i
   a.r.env_ids[k] = i;
 }
 
-// Order (r02): every load in front of the first store (the group's action and target quads, then -- after the ranks -- the
-// dense lanes' initial rows), per-DOF rows of the params in LDS (indexed in place by a run-time column they are vector
-// loads of the argument block): a load issued behind a store waits for that store's round trip.
+// Order (r03; quadcopter.hip has the reasoning): two round trips of loads, neither conditional, both in front of the first
+// store -- trip 1 the flag (clamped index), the byte-table prefix, the group's action and target quads; trip 2, behind the
+// ranks, the dense lanes' initial rows.  The dense lanes' root rows leave last (a wave without a dense lane ends before).
+// Per-DOF rows of the params reach LDS through compile-time indices (indexed by tid they are vector loads of the argument block).
 template <int RANK>
 __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlatPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
@@ -220,7 +221,8 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
   const int64_t base = g * GROUP * FD;
   const int nf4 = (int)(envs_here * FD / 4);
   // ---- loads
-  const bool flagged = env < a.n && a.b.reset_buf[env] != 0;  // :184
+  const int64_t flag_ld = a.b.reset_buf[env < a.n ? env : g * GROUP];  // :184
+  const U8Prefix rp = rank_issue<RANK>(a.b.tile_counts_u8, g, tid);
   float4 av[FD / 4], ct4[FD / 4];
 #pragma unroll
   for (int it = 0; it < FD / 4; ++it) {
@@ -229,34 +231,35 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
     av[it] = *reinterpret_cast<const float4*>(a.actions_in + base + e);
     ct4[it] = LD4S(a.b.current_targets + base + e);  // (reset rows read theirs too and ignore it)
   }
-  if (tid < FD) {
-    s_lo[tid] = p.dof_lower[tid];
-    s_hi[tid] = p.dof_upper[tid];
-    s_def[tid] = p.default_dof_pos[tid];
+  {
+    float lo = 0.f, hi = 0.f, de = 0.f;
+#pragma unroll
+    for (int j = 0; j < FD; ++j) {
+      lo = tid == j ? p.dof_lower[j] : lo;
+      hi = tid == j ? p.dof_upper[j] : hi;
+      de = tid == j ? p.default_dof_pos[j] : de;
+    }
+    if (tid < FD) {
+      s_lo[tid] = lo;
+      s_hi[tid] = hi;
+      s_def[tid] = de;
+    }
   }
+  const bool flagged = env < a.n && flag_ld != 0;
   int k0, cnt;  // offset of the group in the id list, flagged envs in the group
-  const int64_t k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
+  const int64_t k = rank_finish<RANK>(rp, flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
   __syncthreads();
-  wait_loads_done();  // (in front of the dense lanes' block: inside it, waves without a dense lane would skip the wait)
+  // ---- trip 2
   const bool dense = tid < cnt;  // dense lanes: thread j takes the group's j-th flagged env
   const int64_t di = g * GROUP + (dense ? s_list[tid] : 0);
-  float ip[3] = {0.f, 0.f, 0.f};
-  float4 iq = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (dense) {
+  float ip[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) ip[c] = a.r.initial_root_pos[di * 3 + c];
-    iq = *reinterpret_cast<const float4*>(a.r.initial_root_rot + di * 4);
-  }
+  for (int c = 0; c < 3; ++c) ip[c] = a.r.initial_root_pos[di * 3 + c];
+  const float4 iq = *reinterpret_cast<const float4*>(a.r.initial_root_rot + di * 4);
 
   // ---- stores
-  if (dense) {
-    const u4 c{(uint32_t)di, 3u, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};  // draws 12, 13, 14: x, y, yaw
-    const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
-    const float u3[3] = {u01(x.x), u01(x.y), u01(x.z)};
-    anymal_flat_reset_head(a, di, (int64_t)k0 + tid, u3, ip, iq);
-  }
 
   // lane-linear over the group's 256 x 12 floats
 #pragma unroll
@@ -294,6 +297,11 @@ __global__ __launch_bounds__(GROUP) void anymal_flat_pre_kernel(const AnymalFlat
     ST4S(a.b.current_targets + base + e, make_float4(o[0], o[1], o[2], o[3]));
   }
   if (g == G - 1 && tid == 0) *a.r.count = (int64_t)k0 + cnt;
+  if (!dense) return;
+  const u4 c{(uint32_t)di, 3u, (uint32_t)step_of(a.r), (uint32_t)(step_of(a.r) >> 32)};  // draws 12, 13, 14: x, y, yaw
+  const u4 x = philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
+  const float u3[3] = {u01(x.x), u01(x.y), u01(x.z)};
+  anymal_flat_reset_head(a, di, (int64_t)k0 + tid, u3, ip, iq);
 }
 
 

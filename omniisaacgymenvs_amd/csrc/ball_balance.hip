@@ -127,8 +127,30 @@ struct BallPre {
   uint32_t flags;
 };
 
+// the initial rows of env i that reset_idx copies out (:228-246), fetched in one go in front of the caller's first store
+struct BallRows {
+  float bp[3], bot_pos[3], bot_vel[6], dof[BMAXD];
+  float4 bot_rot;
+};
+__device__ __forceinline__ BallRows ball_fetch_rows(const BallPre& a, int64_t i) {
+  const oige_ball_balance_reset_io& r = a.r;
+  const int D = a.p.num_dof;
+  BallRows w;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    w.bp[c] = r.initial_ball_pos[i * 3 + c];
+    w.bot_pos[c] = r.initial_bot_pos[i * 3 + c];
+  }
+  w.bot_rot = *reinterpret_cast<const float4*>(r.initial_bot_rot + i * 4);
+#pragma unroll
+  for (int c = 0; c < 6; ++c) w.bot_vel[c] = r.initial_bot_velocities[i * 6 + c];
+#pragma unroll
+  for (int j = 0; j < BMAXD; ++j) w.dof[j] = r.initial_dof_positions[i * D + (j < D ? j : 0)];  // (no conditional load)
+  return w;
+}
+
 // reset_idx (:208-260) for env i landing in compacted row k; u = the five U[0,1) draws (dists, dirs, hspeeds, vspeeds, height)
-__device__ __forceinline__ void ball_reset_env(const BallPre& a, int64_t i, int64_t k, const float (&u)[5]) {
+__device__ __forceinline__ void ball_reset_env(const BallPre& a, int64_t i, int64_t k, const float (&u)[5], const BallRows& w) {
   const oige_ball_balance_reset_io& r = a.r;
   const int D = a.p.num_dof;
   const float dists = 0.399f * u[0] + 0.001f;                      // torch_rand_float(min_d, max_d)
@@ -137,10 +159,9 @@ __device__ __forceinline__ void ball_reset_env(const BallPre& a, int64_t i, int6
   const float speedscales = (dists - 0.001f) / 0.399f;
   const float hspeeds = 2.0f * u[2] + 0.0f;
   const float vspeeds = -(0.0f * u[3] + 5.0f);
-  const float* bp = r.initial_ball_pos + i * 3;
-  r.ball_pos_out[k * 3 + 0] = bp[0] + dists * dx;
-  r.ball_pos_out[k * 3 + 1] = bp[1] + dists * dy;
-  r.ball_pos_out[k * 3 + 2] = bp[2] + (1.0f * u[4] + 1.0f);
+  r.ball_pos_out[k * 3 + 0] = w.bp[0] + dists * dx;
+  r.ball_pos_out[k * 3 + 1] = w.bp[1] + dists * dy;
+  r.ball_pos_out[k * 3 + 2] = w.bp[2] + (1.0f * u[4] + 1.0f);
   *reinterpret_cast<float4*>(r.ball_rot_out + k * 4) = make_float4(1.f, 0.f, 0.f, 0.f);
   float* bv = r.ball_vel_out + k * 6;
   bv[0] = ((-speedscales) * hspeeds) * dx;
@@ -148,11 +169,13 @@ __device__ __forceinline__ void ball_reset_env(const BallPre& a, int64_t i, int6
   bv[2] = vspeeds;
   bv[3] = bv[4] = bv[5] = 0.0f;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) r.bot_pos_out[k * 3 + c] = r.initial_bot_pos[i * 3 + c];
-  *reinterpret_cast<float4*>(r.bot_rot_out + k * 4) = *reinterpret_cast<const float4*>(r.initial_bot_rot + i * 4);
+  for (int c = 0; c < 3; ++c) r.bot_pos_out[k * 3 + c] = w.bot_pos[c];
+  *reinterpret_cast<float4*>(r.bot_rot_out + k * 4) = w.bot_rot;
 #pragma unroll
-  for (int c = 0; c < 6; ++c) r.bot_vel_out[k * 6 + c] = r.initial_bot_velocities[i * 6 + c];
-  for (int j = 0; j < D; ++j) r.dof_pos_out[k * D + j] = r.initial_dof_positions[i * D + j];
+  for (int c = 0; c < 6; ++c) r.bot_vel_out[k * 6 + c] = w.bot_vel[c];
+#pragma unroll
+  for (int j = 0; j < BMAXD; ++j)
+    if (j < D) r.dof_pos_out[k * D + j] = w.dof[j];
   a.b.reset_buf[i] = 0;
   a.b.progress_buf[i] = 0;
   r.env_ids[k] = i;
@@ -166,6 +189,10 @@ __device__ __forceinline__ void ball_draw(const BallPre& a, int64_t i, float (&u
   u[0] = u01(x.x); u[1] = u01(x.y); u[2] = u01(x.z); u[3] = u01(x.w); u[4] = u01(y.x);
 }
 
+// Two round trips of loads, neither conditional, both in front of the first store (r03; quadcopter.hip has the reasoning):
+// trip 1 the flag (clamped index), the env's own target row and actions, the byte-table prefix; trip 2, behind the ranks, the
+// dense lanes' initial rows (r02 fetched them one by one between the stores of reset_idx: thirteen serial round trips for every
+// workgroup with a flagged env).  The dense lanes' rows leave last; a wave without a dense lane ends before.
 template <int RANK>
 __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
@@ -176,31 +203,32 @@ __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a
   const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
   const bool live = env < a.n;
-  const bool flagged = live && a.b.reset_buf[env] != 0;  // :191
-  // the env's own target row and actions, fetched in front of every store of the kernel (r02: a load issued behind a store
-  // waits for that store's round trip; the r01 loop read and wrote the row element by element)
   const int D = p.num_dof;
   const int64_t le = live ? env : g * GROUP;
+  // ---- trip 1
+  const int64_t flag_ld = a.b.reset_buf[le];  // :191
+  const U8Prefix rp = rank_issue<RANK>(a.b.tile_counts_u8, g, tid);
   float tgv[BMAXD], ain[3];
 #pragma unroll
-  for (int j = 0; j < BMAXD; ++j) tgv[j] = j < D ? a.b.dof_position_targets[le * D + j] : 0.0f;
+  for (int j = 0; j < BMAXD; ++j) tgv[j] = a.b.dof_position_targets[le * D + (j < D ? j : 0)];
 #pragma unroll
   for (int c = 0; c < 3; ++c) ain[c] = a.actions_in[le * 3 + c];
+  const bool flagged = live && flag_ld != 0;
   int k0, cnt;  // offset of the group in the id list, flagged envs in the group
-  const int64_t k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
+  const int64_t k = rank_finish<RANK>(rp, flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   __syncthreads();
-  wait_loads_done();
-  if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env
-    const int64_t i = g * GROUP + s_list[tid];
-    float u[5];
-    ball_draw(a, i, u);
-    ball_reset_env(a, i, (int64_t)k0 + tid, u);
-  }
+  // ---- trip 2: dense lanes, thread j takes the group's j-th flagged env (idle lanes re-read the group's first env)
+  const bool dense = tid < cnt;
+  const int64_t di = g * GROUP + (dense ? s_list[tid] : 0);
+  const BallRows rows = ball_fetch_rows(a, di);
+  // ---- stores
   if (live) {  // :196-204
     float* tg = a.b.dof_position_targets + env * D;
     if (flagged) {
-      for (int j = 0; j < D; ++j) tg[j] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < BMAXD; ++j)
+        if (j < D) tg[j] = 0.0f;
     } else {
       float add[BMAXD];
 #pragma unroll
@@ -224,6 +252,10 @@ __global__ __launch_bounds__(GROUP) void ball_balance_pre_kernel(const BallPre a
     }
   }
   if (g == G - 1 && tid == 0) *a.r.count = (int64_t)k0 + cnt;
+  if (!dense) return;
+  float u[5];
+  ball_draw(a, di, u);
+  ball_reset_env(a, di, (int64_t)k0 + tid, u, rows);
 }
 
 __global__ __launch_bounds__(256) void ball_balance_reset_idx_kernel(const BallPre a, int64_t max_ids) {
@@ -238,7 +270,8 @@ __global__ __launch_bounds__(256) void ball_balance_reset_idx_kernel(const BallP
   } else {
     ball_draw(a, i, u);
   }
-  ball_reset_env(a, i, k, u);
+  const BallRows rows = ball_fetch_rows(a, i);
+  ball_reset_env(a, i, k, u, rows);
 }
 
 static int check_ball(const oige_ball_balance_params* p, const oige_ball_balance_buffers* b, int64_t n, const char* who) {

@@ -135,8 +135,10 @@ struct CfPre {
 __global__ __launch_bounds__(GROUP) void crazyflie_count_kernel(const CfPre a) {
   const int64_t env = (int64_t)blockIdx.x * GROUP + threadIdx.x;
   const bool live = env < a.n;
-  const bool fr = live && a.b.reset_buf[env] != 0;
-  const bool ft = live && (fr || a.b.progress_buf[env] % 500 == 0);
+  const int64_t le = live ? env : 0;
+  const int64_t fr_ld = a.b.reset_buf[le], pg_ld = a.b.progress_buf[le];  // side by side, not conditional (crazyflie_pre_kernel)
+  const bool fr = live & (fr_ld != 0);
+  const bool ft = live & ((fr_ld != 0) | (pg_ld % 500 == 0));
   const unsigned long long mr = __ballot(fr), mt = __ballot(ft);
   if (lane_id() == 0) {
     const int64_t t = env / TILE;
@@ -190,10 +192,11 @@ __global__ __launch_bounds__(GROUP) void crazyflie_pre_kernel(const CfPre a) {
   const int32_t* off_r = a.b.reset_workspace + G * GROUP_TILES;
   const int32_t* off_t = a.b.target_workspace + G * GROUP_TILES;
   const bool live = env < a.n;
-  // ---- every load of the thread first
-  const bool fr = live && a.b.reset_buf[env] != 0;
-  const bool ft = live && (fr || a.b.progress_buf[env] % 500 == 0);
+  // ---- every load of the thread first.  The two flags through a clamped index, side by side (r03: written as `live &&
+  // flag[env]` each was a branch around a load with a full wait behind it -- two serial round trips in front of the rest)
   const int64_t le = live ? env : 0;  // dead lanes shadow env 0, never store
+  const int64_t fr_ld = a.b.reset_buf[le];
+  const int64_t pg_ld = a.b.progress_buf[le];
   const float4 av4 = *reinterpret_cast<const float4*>(a.actions_in + le * 4);
   // (reset envs read their filter states too and ignore them: reset_idx zeroes both, :328-329)
   const float4 cd_in = *reinterpret_cast<const float4*>(a.b.thrust_cmds_damp + le * 4);
@@ -201,6 +204,8 @@ __global__ __launch_bounds__(GROUP) void crazyflie_pre_kernel(const CfPre a) {
   const float4 r4 = *reinterpret_cast<const float4*>(a.root_rot + le * 4);
   const float tn[4] = {a.r.thrust_noise4[0], a.r.thrust_noise4[1], a.r.thrust_noise4[2], a.r.thrust_noise4[3]};  // (a device tensor)
   const int32_t total_r = off_r[G], total_t = off_t[G];
+  const bool fr = live && fr_ld != 0;
+  const bool ft = live & ((fr_ld != 0) | (pg_ld % 500 == 0));  // (bitwise: behind `||` the compiler sinks the second load into a branch)
   float ip[3] = {0.f, 0.f, 0.f}, ep[3] = {0.f, 0.f, 0.f};
   float4 iq = make_float4(0.f, 0.f, 0.f, 0.f), bq = iq;
   float es[CE];

@@ -225,6 +225,11 @@ __device__ __forceinline__ void franka_reset_rows(const FrankaPre& a, int64_t i,
   a.r.env_ids[k] = i;
 }
 
+// Two round trips of loads, both in front of the first store (r03; quadcopter.hip has the reasoning).  Trip 1: the flag
+// (clamped index), the byte-table prefix, the walk's action and target quads.  Trip 2, behind the ranks: the default rows of
+// the props of the group's flagged envs, one prop row per thread over the whole workgroup (r02 copied them prop by prop on
+// the dense lane, a load behind a store each time: num_props serial round trips in every workgroup with a flagged env).
+// The dense lanes' Philox draws stay in front of the walk: it starts the flagged envs' rows from their new positions.
 template <int FD, int RANK>
 __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
@@ -237,9 +242,9 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
   const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
   const bool live = env < a.n;
-  const bool flagged = live && a.b.reset_buf[env] != 0;  // :364
-  // r02: the walk's action and target quads are fetched here, in front of every store of the kernel (a load issued behind a
-  // store waits for that store's round trip; r01 ran reset stores -> row stores -> these loads)
+  // ---- trip 1
+  const int64_t flag_ld = a.b.reset_buf[live ? env : g * GROUP];  // :364
+  const U8Prefix rp = rank_issue<RANK>(a.b.tile_counts_u8, g, tid);
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
   const int total = (int)envs_here * FD;
   const int64_t base = g * GROUP * FD;
@@ -260,8 +265,9 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
         if (e + c < total) { avq[it][c] = a.actions_in[base + e + c]; tvq[it][c] = a.b.franka_dof_targets[base + e + c]; }
     }
   }
+  const bool flagged = live && flag_ld != 0;
   int k0, cnt;  // offset of the group in the id list, flagged envs in the group
-  const int64_t k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
+  const int64_t k = rank_finish<RANK>(rp, flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
 #pragma unroll
@@ -272,18 +278,53 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
       s_rate[j] = p.dof_speed_scales[j] * p.dt;  // left to right: speed_scales * dt * actions * action_scale (:369)
     }
   __syncthreads();
-  wait_loads_done();  // (outside the dense lanes' block: inside it, waves without a dense lane would skip the wait)
 
-  if (tid < cnt) {  // dense lanes: thread j takes the group's j-th flagged env
-    const int il = s_list[tid];
-    const int64_t i = g * GROUP + il;
-    float u[FMAX], pos[FMAX];
-    franka_draws(a, i, u);
-    franka_reset_rows<FD, false>(a, i, (int64_t)k0 + tid, u, pos);
+  // ---- trip 2: prop row e of the group's flagged envs (:401-406) = prop e % P of the (e / P)-th flagged env; thread e takes
+  // it (rows beyond the workgroup's width: the loop at the end).  Not conditional: an idle thread re-reads a valid row, and
+  // without props the actions stand in for the tables
+  const int P = p.num_props;
+  const int prow = cnt * P;  // prop rows of this group
+  const bool has_prop = tid < prow;
+  const int pr = has_prop ? tid / (P > 0 ? P : 1) : 0;
+  const int64_t psrc = P > 0 ? (g * GROUP + (cnt > 0 ? s_list[pr] : 0)) * P + (has_prop ? tid - pr * P : 0) : 0;
+  const float* pp_tab = P > 0 ? a.r.default_prop_pos : a.actions_in;
+  const float* pq_tab = P > 0 ? a.r.default_prop_rot : a.actions_in;
+  float pp[3];
 #pragma unroll
-    for (int j = 0; j < FD; ++j) s_pos[il * FD + j] = pos[j];  // franka_dof_targets[env_ids] = pos (:389)
+  for (int c = 0; c < 3; ++c) pp[c] = pp_tab[psrc * 3 + c];
+  const float4 pq = *reinterpret_cast<const float4*>(pq_tab + psrc * 4);
+
+  const bool dense = tid < cnt;  // dense lanes: thread j takes the group's j-th flagged env
+  const int dl = dense ? s_list[tid] : 0;
+  const int64_t di = g * GROUP + dl;
+  if (dense) {
+    float u[FMAX], pos[FMAX];
+    franka_draws(a, di, u);
+#pragma unroll
+    for (int j = 0; j < FD; ++j) {
+      pos[j] = tensor_clamp(p.default_dof_pos[j] + 0.25f * (u[j] - 0.5f), p.dof_lower[j], p.dof_upper[j]);  // :380-385
+      s_pos[dl * FD + j] = pos[j];  // franka_dof_targets[env_ids] = pos (:389)
+    }
   }
   __syncthreads();
+
+  // ---- stores
+  if (has_prop) {
+    const int64_t dst = (int64_t)k0 * P + tid;
+    a.r.prop_ids[dst] = psrc;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.r.prop_pos_out[dst * 3 + c] = pp[c];
+    *reinterpret_cast<float4*>(a.r.prop_rot_out + dst * 4) = pq;
+  }
+  if (dense) {
+    const int64_t kk = (int64_t)k0 + tid;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(a.r.cabinet_dof_pos_out + kk * CD) = z4;  // :393-398
+    *reinterpret_cast<float4*>(a.r.cabinet_dof_vel_out + kk * CD) = z4;
+    a.b.reset_buf[di] = 0;
+    a.b.progress_buf[di] = 0;
+    a.r.env_ids[kk] = di;
+  }
   {  // view rows k0 .. k0 + cnt of dof_pos_out / dof_vel_out: one contiguous run each, written lane-linearly from s_pos
     const int run = cnt * FD;
     float* dp = a.r.dof_pos_out + (int64_t)k0 * FD;
@@ -323,6 +364,15 @@ __global__ __launch_bounds__(GROUP) void franka_cabinet_pre_kernel(const FrankaP
   if (g == G - 1 && tid == 0) {
     *a.r.count = (int64_t)k0 + cnt;
     *a.r.prop_count = ((int64_t)k0 + cnt) * p.num_props;
+  }
+  // prop rows beyond the workgroup's width (more than 256 / num_props flagged envs in the group): loads behind stores, rare
+  for (int e = tid + GROUP; e < prow; e += GROUP) {
+    const int r = e / P, j = e - r * P;
+    const int64_t src = (g * GROUP + s_list[r]) * P + j, dst = (int64_t)k0 * P + e;
+    a.r.prop_ids[dst] = src;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.r.prop_pos_out[dst * 3 + c] = a.r.default_prop_pos[src * 3 + c];
+    *reinterpret_cast<float4*>(a.r.prop_rot_out + dst * 4) = *reinterpret_cast<const float4*>(a.r.default_prop_rot + src * 4);
   }
 }
 

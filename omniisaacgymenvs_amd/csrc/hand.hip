@@ -947,10 +947,13 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
   // ---- 0: loads.  None is conditional: a lane past the group's end re-reads the group's first float4, a quad that does
   // not need its cur_targets (all four DOFs actuated) re-reads its prev_targets quad, a missing correlated-noise buffer
   // reads the actions again (same lines, already on their way: no HBM traffic)
-  const int64_t f_env_raw = live ? a.b.reset_buf[env] : 0;
-  const int64_t f_goal_raw = live ? a.b.reset_goal_buf[env] : 0;
+  // (the flags too: written as `live ? flag[env] : 0` each became a branch around a load with a full wait behind it -- two
+  // serial round trips in front of everything else; r03)
+  const int64_t env_ld = live ? env : g * GROUP;
+  const int64_t f_env_ld = a.b.reset_buf[env_ld];
+  const int64_t f_goal_ld = a.b.reset_goal_buf[env_ld];
   int cnt_in = 0;
-  if (DR) cnt_in = a.dn.counter[live ? env : 0];
+  if (DR) cnt_in = a.dn.counter[env_ld];
   uint32_t amask = 0;  // uniform: bit j set = DOF j actuated
 #pragma unroll
   for (int t = 0; t < A; ++t) amask |= 1u << p.actuated_dof_indices[t];
@@ -987,13 +990,27 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
   }
 
   // ---- 1: ranks and lists
-  const bool f_env = f_env_raw != 0, f_goal = f_goal_raw != 0;
-  if (tid < D) {
-    s_inv[tid] = -1;
-    s_tab[tid] = p.dof_lower[tid];
-    s_tab[D + tid] = p.dof_upper[tid];
-    s_tab[2 * D + tid] = p.dof_default_pos[tid];
-    s_tab[3 * D + tid] = p.dof_default_vel[tid];
+  const bool f_env = live && f_env_ld != 0, f_goal = live && f_goal_ld != 0;
+  {  // the per-DOF rows of the argument block through compile-time indices (scalar loads: indexed by tid they are VECTOR
+     // loads of the argument block, with a full wait for everything in flight behind them)
+    float lo = 0.f, hi = 0.f, dp = 0.f, dv = 0.f;
+    int inv = -1;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      lo = tid == j ? p.dof_lower[j] : lo;
+      hi = tid == j ? p.dof_upper[j] : hi;
+      dp = tid == j ? p.dof_default_pos[j] : dp;
+      dv = tid == j ? p.dof_default_vel[j] : dv;
+    }
+#pragma unroll
+    for (int t = 0; t < A; ++t) inv = tid == p.actuated_dof_indices[t] ? t : inv;
+    if (tid < D) {
+      s_inv[tid] = inv;
+      s_tab[tid] = lo;
+      s_tab[D + tid] = hi;
+      s_tab[2 * D + tid] = dp;
+      s_tab[3 * D + tid] = dv;
+    }
   }
   int my_cnt = 0;
   if (DR) {  // the wrapper hands the noise the reset_buf as it stands before this step's resets (vec_env_rlgames.py:72-75)
@@ -1006,80 +1023,42 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
   if (f_goal) s_list_g[(int)(kg - k0g)] = tid;
   if (f_env) s_list_r[(int)(kr - k0r)] = tid;
   if (tid < GROUP) s_rank[tid] = f_env ? (int)(kr - k0r) : -1;
-  if (tid < A) s_inv[p.actuated_dof_indices[tid]] = tid;
   __syncthreads();
   // (no wait_loads_done() here: measured 192 -> 198 us; the prev / cur target quads are not needed before phase 4)
 
-  // ---- 2: dense resets, spread over the workgroup's waves so that no wave carries more than one Philox-and-rotation job
-  // (all on the first wave they were 2100 issue slots in front of the barrier below): reset_idx's object rows and flags on
-  // lanes 0.., goal-only envs on lanes 64.., reset_idx's nested reset_target_pose on lanes 128.., the DOF-row / correlated
-  // noise re-draws from lane DOFF on.  Rows fetched first (the only loads left), then the draws, then the stores.
+  // ---- 2: the flagged envs' jobs on DENSE lanes: reset_idx's object rows and flags on lanes 0.., goal-only envs on lanes
+  // 64.., reset_idx's nested reset_target_pose on lanes 128.. (three different waves).  Only their ROWS are fetched here (the
+  // kernel's second and last round trip of loads, issued in front of every store); the jobs themselves -- two Philox blocks,
+  // four sincos, scattered stores -- run behind phase 6, where no other wave waits for them (r03: in front of the barrier
+  // below they were 2-4 us of every workgroup's ~20 us life).  A lane's first role keeps its two rows in registers; a lane
+  // with a second role (more than 64 flagged envs in the group: the step after a full reset) fetches that role's rows late.
+  const int tg = (tid + HPNT - WAVE) & (HPNT - 1), trg = (tid + HPNT - 2 * WAVE) & (HPNT - 1);
+  static_assert((HPNT & (HPNT - 1)) == 0 && HPNT >= 256, "lane rotations assume a power-of-two workgroup of at least four waves");
+  const bool do_r = tid < cntr, do_g = tg < cntg, do_rg = trg < cntr;
+  const int il_r = do_r ? s_list_r[tid] : 0, il_g = do_g ? s_list_g[tg] : 0, il_rg = do_rg ? s_list_r[trg] : 0;
+  const int64_t ir = g * GROUP + il_r, ig = g * GROUP + il_g, irg = g * GROUP + il_rg;
+  const bool g_keeps_rot = do_g && s_rank[il_g] < 0;
+  const int role = do_r ? 0 : do_g ? 1 : do_rg ? 2 : -1;
+  float row_a[3], row_b[3];  // role 0: env_pos, object_init_pos; roles 1, 2: goal_init_pos, env_pos
+  {  // unconditional (a lane without a role re-reads the group's first env: one request for all of them): inside a
+     // conditional block the block's join would wait for the rows right here
+    const int64_t i1 = role == 0 ? ir : role == 1 ? ig : role == 2 ? irg : g * GROUP;
+    const float* src_a = role == 0 ? a.r.env_pos : a.r.goal_init_pos;
+    const float* src_b = role == 0 ? a.r.object_init_pos : a.r.env_pos;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      row_a[c] = src_a[i1 * 3 + c];
+      row_b[c] = src_b[i1 * 3 + c];
+    }
+  }
+  if (DR && live) a.dn.counter[env] = my_cnt;  // (behind every load of this thread)
   {
-    constexpr int DOFF = HPNT >= 512 ? 256 : 192;
-    const int tg = (tid + HPNT - WAVE) & (HPNT - 1), trg = (tid + HPNT - 2 * WAVE) & (HPNT - 1), td = (tid + HPNT - DOFF) & (HPNT - 1);
-    static_assert((HPNT & (HPNT - 1)) == 0 && HPNT >= 256, "lane rotations assume a power-of-two workgroup of at least four waves");
-    const bool do_r = tid < cntr, do_g = tg < cntg, do_rg = trg < cntr;
-    const int il_r = do_r ? s_list_r[tid] : 0, il_g = do_g ? s_list_g[tg] : 0, il_rg = do_rg ? s_list_r[trg] : 0;
-    const int64_t ir = g * GROUP + il_r, ig = g * GROUP + il_g, irg = g * GROUP + il_rg;
-    float ep_r[3] = {0.f, 0.f, 0.f}, oi_r[3] = {0.f, 0.f, 0.f};
-    float gi_g[3] = {0.f, 0.f, 0.f}, ep_g[3] = {0.f, 0.f, 0.f};
-    if (do_r) {
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        ep_r[c] = a.r.env_pos[ir * 3 + c];
-        oi_r[c] = a.r.object_init_pos[ir * 3 + c];
-      }
-    }
-    if (do_g || do_rg) {  // (a lane is on at most one of the two lists unless the group holds more than 192 of either)
-      const int64_t ii = do_g ? ig : irg;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        gi_g[c] = a.r.goal_init_pos[ii * 3 + c];
-        ep_g[c] = a.r.env_pos[ii * 3 + c];
-      }
-    }
-    if (DR && live) a.dn.counter[env] = my_cnt;  // (behind every load of this thread)
-    if (do_g) {  // goal-only ids (:324-327); an env that is in both lists keeps reset_idx's rotation (:328-329)
-      float u[4];
-      hand_draw<4>(a.r, ig, 0u, u);
-      hand_goal_write(a, ig, (int64_t)k0g + tg, u[0], u[1], gi_g, ep_g, s_rank[il_g] < 0, a.r.goal_world_pos_out, a.r.goal_rot_out);
-      a.r.goal_ids[k0g + tg] = ig;
-    }
-    if (do_rg) {  // reset_idx's reset_target_pose (:401)
-      float gi2[3], ep2[3];
-      if (do_g) {  // the lane also held a goal-only env: its rows belong to that one, fetch this env's
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          gi2[c] = a.r.goal_init_pos[irg * 3 + c];
-          ep2[c] = a.r.env_pos[irg * 3 + c];
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { gi2[c] = gi_g[c]; ep2[c] = ep_g[c]; }
-      }
-      float ug[4];
-      hand_draw<4>(a.r, irg, 2u, ug);
-      hand_goal_write(a, irg, (int64_t)k0r + trg, ug[0], ug[1], gi2, ep2, true, a.r.r_goal_world_pos_out, a.r.r_goal_rot_out);
-    }
-    if (do_r) {  // reset_idx (:397-441) without its DOF rows and its goal
-      const int64_t k = (int64_t)k0r + tid;
-      float u[8];
-      hand_draw<8>(a.r, ir, 1u, u);  // draws 0..4 of the (n,53) table
-#pragma unroll
-      for (int c = 0; c < 3; ++c) a.r.object_pos_out[k * 3 + c] = (oi_r[c] + p.reset_position_noise * u[c]) + ep_r[c];  // :404-406
-      const q4 orot = randomize_rotation(u[3], u[4]);                                                             // :408-410
-      *reinterpret_cast<float4*>(a.r.object_rot_out + k * 4) = make_float4(orot.w, orot.x, orot.y, orot.z);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) a.r.object_vel_out[k * 6 + c] = 0.0f;  // :412-413
-      a.b.progress_buf[ir] = 0;  // :439-441
-      a.b.reset_buf[ir] = 0;
-      a.b.successes[ir] = 0.0f;
-      a.r.env_ids[k] = ir;
-    }
     // DOF rows of the first HAND_RMAX reset envs, one float4 per lane, into LDS (their compacted rows leave in phase 6:
-    // stores issued here would sit in front of phase 3's first use of the loaded actions)
+    // stores issued here would sit in front of phase 3's first use of the loaded actions); the correlated-noise samples
+    // start half a workgroup further on, so that the two kinds of draw run on different waves
+    const int tc = (tid + HPNT / 2) & (HPNT - 1);
     const int nr = cntr < HAND_RMAX ? cntr : HAND_RMAX;
-    for (int w = td; w < nr * (D / 4); w += HPNT) {
+    for (int w = tid; w < nr * (D / 4); w += HPNT) {
       const int r = w / (D / 4), j0 = 4 * (w - r * (D / 4));
       float pos[4], vel[4];
       hand_redraw_quad(a, tab, g * GROUP + s_list_r[r], D, j0, pos, vel);
@@ -1087,7 +1066,7 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
       *reinterpret_cast<float4*>(s_rvel + r * D + j0) = make_float4(vel[0], vel[1], vel[2], vel[3]);
     }
     if (DR && has_cor) {  // correlated_noise_buffer[reset_ids] = sample (randomize.py:379-400), same Philox key as noise_apply4
-      for (int w = td; w < nr * (A / 4); w += HPNT) {
+      for (int w = tc; w < nr * (A / 4); w += HPNT) {
         const int r = w / (A / 4), q = w - r * (A / 4);
         const int64_t gf = (base_a >> 2) + (int64_t)s_list_r[r] * (A / 4) + q;
         float sr[4];
@@ -1213,6 +1192,50 @@ __global__ __launch_bounds__(HPNT) OIGE_HAND_PRE_OCC void hand_pre_kernel(const 
   if (g == 0 && tid == 0) {
     *a.r.count = (int64_t)off_r[G];
     *a.r.goal_count = (int64_t)off_g[G];
+  }
+  // ---- 7: the dense jobs (rows fetched in phase 2).  A wave without one ends here.
+  if (role < 0) return;
+  if (do_r) {  // reset_idx (:397-441) without its DOF rows and its goal
+    const int64_t k = (int64_t)k0r + tid;
+    float u[8];
+    hand_draw<8>(a.r, ir, 1u, u);  // draws 0..4 of the (n,53) table
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.r.object_pos_out[k * 3 + c] = (row_b[c] + p.reset_position_noise * u[c]) + row_a[c];  // :404-406
+    const q4 orot = randomize_rotation(u[3], u[4]);                                                               // :408-410
+    *reinterpret_cast<float4*>(a.r.object_rot_out + k * 4) = make_float4(orot.w, orot.x, orot.y, orot.z);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a.r.object_vel_out[k * 6 + c] = 0.0f;  // :412-413
+    a.b.progress_buf[ir] = 0;  // :439-441
+    a.b.reset_buf[ir] = 0;
+    a.b.successes[ir] = 0.0f;
+    a.r.env_ids[k] = ir;
+  }
+  if (do_g) {  // goal-only ids (:324-327); an env that is in both lists keeps reset_idx's rotation (:328-329)
+    float gi[3], ep[3];
+    if (role == 1) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { gi[c] = row_a[c]; ep[c] = row_b[c]; }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { gi[c] = a.r.goal_init_pos[ig * 3 + c]; ep[c] = a.r.env_pos[ig * 3 + c]; }
+    }
+    float u[4];
+    hand_draw<4>(a.r, ig, 0u, u);
+    hand_goal_write(a, ig, (int64_t)k0g + tg, u[0], u[1], gi, ep, g_keeps_rot, a.r.goal_world_pos_out, a.r.goal_rot_out);
+    a.r.goal_ids[k0g + tg] = ig;
+  }
+  if (do_rg) {  // reset_idx's reset_target_pose (:401)
+    float gi[3], ep[3];
+    if (role == 2) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { gi[c] = row_a[c]; ep[c] = row_b[c]; }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { gi[c] = a.r.goal_init_pos[irg * 3 + c]; ep[c] = a.r.env_pos[irg * 3 + c]; }
+    }
+    float ug[4];
+    hand_draw<4>(a.r, irg, 2u, ug);
+    hand_goal_write(a, irg, (int64_t)k0r + trg, ug[0], ug[1], gi, ep, true, a.r.r_goal_world_pos_out, a.r.r_goal_rot_out);
   }
 }
 

@@ -113,8 +113,10 @@ struct IngPre {
 __global__ __launch_bounds__(GROUP) void ingenuity_count_kernel(const IngPre a) {
   const int64_t env = (int64_t)blockIdx.x * GROUP + threadIdx.x;
   const bool live = env < a.n;
-  const bool fr = live && a.b.reset_buf[env] != 0;
-  const bool ft = live && (fr || a.b.progress_buf[env] % 500 == 0);
+  const int64_t le = live ? env : 0;
+  const int64_t fr_ld = a.b.reset_buf[le], pg_ld = a.b.progress_buf[le];  // side by side, not conditional (ingenuity_pre_kernel)
+  const bool fr = live & (fr_ld != 0);
+  const bool ft = live & ((fr_ld != 0) | (pg_ld % 500 == 0));
   const unsigned long long mr = __ballot(fr), mt = __ballot(ft);
   if (lane_id() == 0) {
     const int64_t t = env / TILE;
@@ -130,18 +132,42 @@ __device__ __forceinline__ u4 ing_block(const IngPre& a, int64_t i, uint32_t blk
   return philox4x32_10(c, (uint32_t)a.r.seed, (uint32_t)(a.r.seed >> 32));
 }
 
+// the rows reset_idx / set_targets read for env i, fetched by the caller in front of its first store
+struct IngResetRows {
+  float4 dp, iq;
+  float ip[3];
+};
+struct IngTargetRows {
+  float4 bq;
+  float ep[3];
+};
+__device__ __forceinline__ IngResetRows ing_fetch_reset(const IngPre& a, int64_t i) {
+  IngResetRows w;
+  w.dp = *reinterpret_cast<const float4*>(a.b.dof_pos + i * 4);
+  w.iq = *reinterpret_cast<const float4*>(a.r.initial_root_rot + i * 4);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) w.ip[c] = a.r.initial_root_pos[i * 3 + c];
+  return w;
+}
+__device__ __forceinline__ IngTargetRows ing_fetch_target(const IngPre& a, int64_t i) {
+  IngTargetRows w;
+  w.bq = *reinterpret_cast<const float4*>(a.r.initial_ball_rot + i * 4);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) w.ep[c] = a.r.env_pos[i * 3 + c];
+  return w;
+}
+
 // reset_idx (:225-249) for env i -> compacted row k; u = dof1, dof3, x, y, z draws
-__device__ __forceinline__ void ing_reset_env(const IngPre& a, int64_t i, int64_t k, const float (&u)[5]) {
-  float4 dp = *reinterpret_cast<const float4*>(a.b.dof_pos + i * 4);
+__device__ __forceinline__ void ing_reset_env(const IngPre& a, int64_t i, int64_t k, const float (&u)[5], const IngResetRows& w) {
+  float4 dp = w.dp;
   dp.y = 0.4f * u[0] + (-0.2f);
   dp.w = 0.4f * u[1] + (-0.2f);
   *reinterpret_cast<float4*>(a.b.dof_pos + i * 4) = dp;
   *reinterpret_cast<float4*>(a.r.dof_pos_out + k * 4) = dp;
   *reinterpret_cast<float4*>(a.r.dof_vel_out + k * 4) = make_float4(0.f, 0.f, 0.f, 0.f);  // dof_vel[env_ids, :] = 0 (:230)
-  const float* ip = a.r.initial_root_pos + i * 3;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) a.r.root_pos_out[k * 3 + c] = ip[c] + (1.0f * u[2 + c] + (-0.5f));
-  *reinterpret_cast<float4*>(a.r.root_rot_out + k * 4) = *reinterpret_cast<const float4*>(a.r.initial_root_rot + i * 4);
+  for (int c = 0; c < 3; ++c) a.r.root_pos_out[k * 3 + c] = w.ip[c] + (1.0f * u[2 + c] + (-0.5f));
+  *reinterpret_cast<float4*>(a.r.root_rot_out + k * 4) = w.iq;
 #pragma unroll
   for (int c = 0; c < 6; ++c) a.r.root_vel_out[k * 6 + c] = 0.0f;
   a.b.reset_buf[i] = 0;
@@ -150,19 +176,22 @@ __device__ __forceinline__ void ing_reset_env(const IngPre& a, int64_t i, int64_
 }
 
 // set_targets (:213-223) for env i -> compacted row k; u = x, y, z draws
-__device__ __forceinline__ void ing_set_target(const IngPre& a, int64_t i, int64_t k, const float (&u)[3]) {
+__device__ __forceinline__ void ing_set_target(const IngPre& a, int64_t i, int64_t k, const float (&u)[3], const IngTargetRows& w) {
   const float tx = u[0] * 2.0f - 1.0f, ty = u[1] * 2.0f - 1.0f, tz = u[2] + 1.0f;
   float* tp = a.b.target_positions + i * 3;
   tp[0] = tx; tp[1] = ty; tp[2] = tz;
-  const float* ep = a.r.env_pos + i * 3;
-  a.r.ball_pos_out[k * 3 + 0] = tx + ep[0];
-  a.r.ball_pos_out[k * 3 + 1] = ty + ep[1];
-  a.r.ball_pos_out[k * 3 + 2] = (tz + ep[2]) + 0.4f;
-  *reinterpret_cast<float4*>(a.r.ball_rot_out + k * 4) = *reinterpret_cast<const float4*>(a.r.initial_ball_rot + i * 4);
+  a.r.ball_pos_out[k * 3 + 0] = tx + w.ep[0];
+  a.r.ball_pos_out[k * 3 + 1] = ty + w.ep[1];
+  a.r.ball_pos_out[k * 3 + 2] = (tz + w.ep[2]) + 0.4f;
+  *reinterpret_cast<float4*>(a.r.ball_rot_out + k * 4) = w.bq;
   a.r.target_ids[k] = i;
 }
 
 // RANK: where the two lists' group offsets come from (oige_common.hpp: the scan launch, the int32 tile counts, their byte twins)
+// Two round trips of loads, neither conditional, both in front of the first store (r03; quadcopter.hip has the reasoning):
+// trip 1 the two flags side by side (clamped index), both byte-table prefixes, the env's own actions and DOF velocities; trip 2,
+// behind the ranks, the rows of the dense lanes' two jobs.  The jobs themselves (Philox, scattered stores) run last; a wave
+// without a dense lane ends before.
 template <int RANK>
 __global__ __launch_bounds__(GROUP) void ingenuity_pre_kernel(const IngPre a) {
   __shared__ int lds_a[2 * GROUP_TILES], lds_b[2 * GROUP_TILES];
@@ -173,33 +202,27 @@ __global__ __launch_bounds__(GROUP) void ingenuity_pre_kernel(const IngPre a) {
   const int64_t env = g * GROUP + tid;
   const int64_t G = num_groups(a.n);
   const bool live = env < a.n;
-  const bool fr = live && a.b.reset_buf[env] != 0;
-  const bool ft = live && (fr || a.b.progress_buf[env] % 500 == 0);
-  // the env's own rows, fetched in front of every store of the kernel (r02: a load issued behind a store waits for that
-  // store's round trip; reset envs read their actions too and ignore them)
   const int64_t le = live ? env : g * GROUP;
+  // ---- trip 1 (reset envs read their actions too and ignore them)
+  const int64_t fr_ld = a.b.reset_buf[le], pg_ld = a.b.progress_buf[le];
+  const U8Prefix rpr = rank_issue<RANK>(a.b.reset_counts_u8, g, tid), rpt = rank_issue<RANK>(a.b.target_counts_u8, g, tid);
   const float2* ar = reinterpret_cast<const float2*>(a.actions_in + le * 6);
   const float2 a0 = ar[0], a1 = ar[1], a2 = ar[2];
   const float4 dv_in = *reinterpret_cast<const float4*>(a.b.dof_vel + le * 4);
+  const bool fr = live & (fr_ld != 0);
+  const bool ft = live & ((fr_ld != 0) | (pg_ld % 500 == 0));  // (bitwise: behind `||` the compiler sinks the second load into a branch)
   int k0r, cntr, k0t, cntt;
-  const int64_t kr = group_rank_mode<RANK>(fr, a.b.reset_workspace, a.b.reset_counts_u8, G, g, lds_a, k0r, cntr);
-  const int64_t kt = group_rank_mode<RANK>(ft, a.b.target_workspace, a.b.target_counts_u8, G, g, lds_b, k0t, cntt);
+  const int64_t kr = rank_finish<RANK>(rpr, fr, a.b.reset_workspace, a.b.reset_counts_u8, G, g, lds_a, k0r, cntr);
+  const int64_t kt = rank_finish<RANK>(rpt, ft, a.b.target_workspace, a.b.target_counts_u8, G, g, lds_b, k0t, cntt);
   if (fr) s_list_r[(int)(kr - k0r)] = tid;
   if (ft) s_list_t[(int)(kt - k0t)] = tid;
   __syncthreads();
-  wait_loads_done();
-  if (tid < cntr) {  // dense lanes: reset_idx
-    const int64_t i = g * GROUP + s_list_r[tid];
-    const u4 x = ing_block(a, i, 0u), y = ing_block(a, i, 1u);
-    const float u[5] = {u01(x.x), u01(x.y), u01(x.z), u01(x.w), u01(y.x)};
-    ing_reset_env(a, i, (int64_t)k0r + tid, u);
-  }
-  if (tid < cntt) {  // dense lanes: set_targets
-    const int64_t i = g * GROUP + s_list_t[tid];
-    const u4 x = ing_block(a, i, 2u);
-    const float u[3] = {u01(x.x), u01(x.y), u01(x.z)};
-    ing_set_target(a, i, (int64_t)k0t + tid, u);
-  }
+  // ---- trip 2: dense lanes (thread j takes the j-th env of each list; idle lanes re-read the group's first env)
+  const bool dense_r = tid < cntr, dense_t = tid < cntt;
+  const int64_t ir = g * GROUP + (dense_r ? s_list_r[tid] : 0), it = g * GROUP + (dense_t ? s_list_t[tid] : 0);
+  const IngResetRows rr = ing_fetch_reset(a, ir);
+  const IngTargetRows tr = ing_fetch_target(a, it);
+  // ---- stores
   if (live) {  // :162-185
     float th[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (!fr) {
@@ -232,6 +255,17 @@ __global__ __launch_bounds__(GROUP) void ingenuity_pre_kernel(const IngPre a) {
     *a.r.count = (int64_t)k0r + cntr;
     *a.r.target_count = (int64_t)k0t + cntt;
   }
+  if (!(dense_r | dense_t)) return;
+  if (dense_r) {  // reset_idx
+    const u4 x = ing_block(a, ir, 0u), y = ing_block(a, ir, 1u);
+    const float u[5] = {u01(x.x), u01(x.y), u01(x.z), u01(x.w), u01(y.x)};
+    ing_reset_env(a, ir, (int64_t)k0r + tid, u, rr);
+  }
+  if (dense_t) {  // set_targets
+    const u4 x = ing_block(a, it, 2u);
+    const float u[3] = {u01(x.x), u01(x.y), u01(x.z)};
+    ing_set_target(a, it, (int64_t)k0t + tid, u, tr);
+  }
 }
 
 // reset_idx(env_ids) / set_targets(env_ids) with caller-provided ids and (optionally) pre-drawn U[0,1)
@@ -248,7 +282,7 @@ __global__ __launch_bounds__(256) void ingenuity_reset_idx_kernel(const IngPre a
     const u4 x = ing_block(a, i, 0u), y = ing_block(a, i, 1u);
     u[0] = u01(x.x); u[1] = u01(x.y); u[2] = u01(x.z); u[3] = u01(x.w); u[4] = u01(y.x);
   }
-  ing_reset_env(a, i, k, u);
+  ing_reset_env(a, i, k, u, ing_fetch_reset(a, i));
 }
 
 __global__ __launch_bounds__(256) void ingenuity_set_targets_kernel(const IngPre a, int64_t max_ids) {
@@ -264,7 +298,7 @@ __global__ __launch_bounds__(256) void ingenuity_set_targets_kernel(const IngPre
     const u4 x = ing_block(a, i, 2u);
     u[0] = u01(x.x); u[1] = u01(x.y); u[2] = u01(x.z);
   }
-  ing_set_target(a, i, k, u);
+  ing_set_target(a, i, k, u, ing_fetch_target(a, i));
 }
 
 static int check_ing(const oige_ingenuity_params* p, const oige_ingenuity_buffers* b, int64_t n, const char* who) {

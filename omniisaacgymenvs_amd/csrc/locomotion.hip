@@ -436,37 +436,6 @@ __device__ __forceinline__ void reset_env(const oige_locomotion_params& p, const
   r.env_ids[k] = i;
 }
 
-// One pass over the byte table (oige_common.hpp: tile_counts_u8): up to UNSCANNED_U8_MAX_GROUPS groups the four 16-byte chunks
-// a thread takes cover every word in front of any group, so the loads are issued in one go with the kernel's other loads and
-// summed when they have arrived (u8_words_partial's loop puts a full wait inside its body).
-static_assert(UNSCANNED_U8_MAX_GROUPS <= 4 * 4 * GROUP, "one pass of four chunks per thread must cover the table");
-struct U8Prefix {
-  uint4 c[4];
-};
-__device__ __forceinline__ U8Prefix u8_prefix_issue(const uint8_t* counts_u8, int64_t g, int tid) {
-  const uint4* c4 = reinterpret_cast<const uint4*>(counts_u8);
-  const int nq = (int)((g + 3) / 4);  // chunks that hold words [0, g)
-  U8Prefix p;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {  // idle slots re-read a valid chunk: no load inside a conditional block
-    const int j = tid + u * GROUP;
-    p.c[u] = c4[j < nq ? j : (nq > 0 ? nq - 1 : 0)];
-  }
-  return p;
-}
-__device__ __forceinline__ int u8_prefix_sum(const U8Prefix& p, int64_t g, int tid) {
-  unsigned part = 0;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int64_t w0 = 4 * (int64_t)(tid + u * GROUP);  // first word of the chunk; words >= g belong to this group or later ones
-    part = __builtin_amdgcn_sad_u8(w0 < g ? p.c[u].x : 0u, 0u, part);
-    part = __builtin_amdgcn_sad_u8(w0 + 1 < g ? p.c[u].y : 0u, 0u, part);
-    part = __builtin_amdgcn_sad_u8(w0 + 2 < g ? p.c[u].z : 0u, 0u, part);
-    part = __builtin_amdgcn_sad_u8(w0 + 3 < g ? p.c[u].w : 0u, 0u, part);
-  }
-  return wave_sum((int)part);
-}
-
 // pre_physics_step of one 256-env group.  A workgroup's life is a chain of memory round trips (microseconds each under
 // load), and the kernel's rate is resident workgroups x bytes per workgroup / that lifetime, so the chain is kept to TWO:
 //   trip 1  the reset flags, the tile counts in front of the group and the action quads, issued together, nothing
@@ -527,8 +496,8 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
 
   // ---- trip 1
   const int64_t flag_raw = PART == 1 ? 0 : a.b.reset_buf[env < a.n ? env : a.n - 1];
-  U8Prefix pre;
-  if (RANK == RANK_U8 && PART != 1) pre = u8_prefix_issue(a.b.tile_counts_u8, g, tid);
+  U8Prefix pre{};
+  if (PART != 1) pre = rank_issue<RANK>(a.b.tile_counts_u8, g, tid);
   float v[ITS][4];
   if (PART == 2) {
   } else if (full) {
@@ -561,27 +530,8 @@ __global__ __launch_bounds__(GROUP) void locomotion_pre_kernel(const LocoPre a) 
   int64_t k = -1;
   if (PART == 1) {
     __syncthreads();
-  } else if (RANK == RANK_U8) {
-    const int front = u8_prefix_sum(pre, g, tid);
-    const unsigned long long mask = __ballot(flagged);
-    const int w = tid >> 6;
-    if (lane_id() == 0) {
-      lds8[w] = __popcll(mask);
-      lds8[GROUP_TILES + w] = front;
-    }
-    __syncthreads();
-    int before = 0;
-    k0 = 0;
-    cnt = 0;
-#pragma unroll
-    for (int i = 0; i < GROUP_TILES; ++i) {
-      before += (i < w) ? lds8[i] : 0;
-      cnt += lds8[i];
-      k0 += lds8[GROUP_TILES + i];
-    }
-    k = flagged ? (int64_t)k0 + before + rank_below(mask) : -1;
   } else {
-    k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
+    k = rank_finish<RANK>(pre, flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   }
   if (flagged) s_list[(int)(k - k0)] = tid;
   if (PART != 1 && g == G - 1 && tid == 0) *a.r.count = (int64_t)k0 + cnt;

@@ -292,8 +292,10 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   const int64_t abase = g * GROUP * A, tbase = g * GROUP * D;
   constexpr int AIT = (GROUP * A / 4 + GROUP - 1) / GROUP, TIT = (GROUP * D / 4 + GROUP - 1) / GROUP;
 
-  // ---- 0: loads
-  const bool flagged = live && a.b.reset_buf[env] != 0;
+  // ---- 0: loads (the flag through a clamped index: written as `live && flag[env]` it was a branch around a load with a full
+  // wait behind it, a serial round trip in front of everything else; r03)
+  const int64_t flag_ld = a.b.reset_buf[live ? env : g * GROUP];
+  const U8Prefix rp = rank_issue<RANK>(a.b.tile_counts_u8, g, tid);
   float av[AIT][4], tv[TIT][4];
 #pragma unroll
   for (int it = 0; it < AIT; ++it) {
@@ -323,8 +325,9 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   }
 
   // ---- 1: ranks, lists, per-joint tables
+  const bool flagged = live && flag_ld != 0;
   int k0, cnt;  // offset of the group in the id list, flagged envs in the group
-  const int64_t k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
+  const int64_t k = rank_finish<RANK>(rp, flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
 #pragma unroll
@@ -347,6 +350,21 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
   // ---- 2: resets on dense lanes: thread j takes the group's j-th flagged env; its new joint row goes to LDS row j (past
   // NH_RMAX: straight to memory)
   wait_loads_done();
+  // the kernel's second and last round trip of loads, in front of every store: prop row e of the group's flagged envs = prop
+  // e % P of the (e / P)-th flagged env, thread e takes it (rows beyond the workgroup's width: the loop at the end).  Not
+  // conditional: an idle thread re-reads a valid row, and without props the actions stand in for the tables.  (r02 fetched
+  // these rows at the end of the kernel, behind all of its stores: a third round trip, and a fourth for the rows' own stores.)
+  const int P = p.num_props;
+  const int prow = cnt * P;
+  const bool has_prop = tid < prow;
+  const int pr = has_prop ? tid / (P > 0 ? P : 1) : 0;
+  const int64_t psrc = P > 0 ? (g * GROUP + (cnt > 0 ? s_list[pr] : 0)) * P + (has_prop ? tid - pr * P : 0) : 0;
+  const float* pp_tab = P > 0 ? a.r.default_prop_pos : a.actions_in;
+  const float* pq_tab = P > 0 ? a.r.default_prop_rot : a.actions_in;
+  float pp[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) pp[c] = pp_tab[psrc * 3 + c];
+  const float4 pq = *reinterpret_cast<const float4*>(pq_tab + psrc * 4);
   if (tid < cnt) {
     const int64_t i = g * GROUP + s_list[tid], kk = (int64_t)k0 + tid;
     float u[NMAX + 2];
@@ -361,6 +379,18 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
         a.r.dof_vel_out[kk * D + j] = 0.0f;
       }
     }
+  }
+  // the prop rows leave in front of every other store: here the wait for their loads is a wait for loads alone (behind stores
+  // it would also be the wait for those stores' acknowledgement: one in-order counter), and it overlaps the dense lanes' draws
+  if (has_prop) {
+    const int64_t dst = (int64_t)k0 * P + tid;
+    a.r.prop_ids[dst] = psrc;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.r.prop_pos_out[dst * 3 + c] = pp[c];
+    *reinterpret_cast<float4*>(a.r.prop_rot_out + dst * 4) = pq;
+  }
+  if (tid < cnt) {
+    const int64_t i = g * GROUP + s_list[tid], kk = (int64_t)k0 + tid;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(a.r.cabinet_dof_pos_out + kk * 4) = z4;
     *reinterpret_cast<float4*>(a.r.cabinet_dof_vel_out + kk * 4) = z4;
@@ -444,19 +474,15 @@ __global__ __launch_bounds__(GROUP) void newhand_cabinet_pre_kernel(const NhPre 
     *a.r.count = (int64_t)k0 + cnt;
     *a.r.prop_count = ((int64_t)k0 + cnt) * p.num_props;
   }
-  // ---- 6: prop rows of the reset envs, one prop per lane.  Last: these loads sit behind the kernel's stores, and nothing waits
-  // for this part
-  {
-    const int P = p.num_props;
-    for (int w = tid; w < cnt * P; w += GROUP) {
-      const int r = w / P, j = w - r * P;
-      const int64_t src = (g * GROUP + s_list[r]) * P + j, dst = ((int64_t)k0 + r) * P + j;
-      const float px = a.r.default_prop_pos[src * 3], py = a.r.default_prop_pos[src * 3 + 1], pz = a.r.default_prop_pos[src * 3 + 2];
-      const float4 pr = *reinterpret_cast<const float4*>(a.r.default_prop_rot + src * 4);
-      a.r.prop_ids[dst] = src;
-      a.r.prop_pos_out[dst * 3] = px; a.r.prop_pos_out[dst * 3 + 1] = py; a.r.prop_pos_out[dst * 3 + 2] = pz;
-      *reinterpret_cast<float4*>(a.r.prop_rot_out + dst * 4) = pr;
-    }
+  // ---- 6: prop rows beyond the workgroup's width (more than 256 / num_props flagged envs in the group): loads behind stores, rare
+  for (int w = tid + GROUP; w < prow; w += GROUP) {
+    const int r = w / P, j = w - r * P;
+    const int64_t src = (g * GROUP + s_list[r]) * P + j, dst = ((int64_t)k0 + r) * P + j;
+    const float px = a.r.default_prop_pos[src * 3], py = a.r.default_prop_pos[src * 3 + 1], pz = a.r.default_prop_pos[src * 3 + 2];
+    const float4 prq = *reinterpret_cast<const float4*>(a.r.default_prop_rot + src * 4);
+    a.r.prop_ids[dst] = src;
+    a.r.prop_pos_out[dst * 3] = px; a.r.prop_pos_out[dst * 3 + 1] = py; a.r.prop_pos_out[dst * 3 + 2] = pz;
+    *reinterpret_cast<float4*>(a.r.prop_rot_out + dst * 4) = prq;
   }
 }
 

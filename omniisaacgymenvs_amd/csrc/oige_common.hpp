@@ -222,6 +222,70 @@ __device__ __forceinline__ int64_t group_rank_mode(bool flagged, const int32_t* 
   return group_rank_of<RANK == RANK_SCANNED>(flagged, ws, G, g, lds8, k0, cnt);
 }
 
+// The byte-table prefix in ONE pass, split in two so that its loads leave together with a kernel's other loads and are summed
+// when they have arrived (u8_words_partial's loop puts a full wait inside its body): up to UNSCANNED_U8_MAX_GROUPS groups the
+// four 16-byte chunks a thread takes cover every word in front of any group.
+static_assert(UNSCANNED_U8_MAX_GROUPS <= 4 * 4 * GROUP, "one pass of four chunks per thread must cover the table");
+struct U8Prefix {
+  uint4 c[4];
+};
+__device__ __forceinline__ U8Prefix u8_prefix_issue(const uint8_t* counts_u8, int64_t g, int tid) {
+  const uint4* c4 = reinterpret_cast<const uint4*>(counts_u8);
+  const int nq = (int)((g + 3) / 4);  // chunks that hold words [0, g)
+  U8Prefix p;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {  // idle slots re-read a valid chunk: no load inside a conditional block
+    const int j = tid + u * GROUP;
+    p.c[u] = c4[j < nq ? j : (nq > 0 ? nq - 1 : 0)];
+  }
+  return p;
+}
+__device__ __forceinline__ int u8_prefix_sum(const U8Prefix& p, int64_t g, int tid) {
+  unsigned part = 0;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t w0 = 4 * (int64_t)(tid + u * GROUP);  // first word of the chunk; words >= g belong to this group or later ones
+    part = __builtin_amdgcn_sad_u8(w0 < g ? p.c[u].x : 0u, 0u, part);
+    part = __builtin_amdgcn_sad_u8(w0 + 1 < g ? p.c[u].y : 0u, 0u, part);
+    part = __builtin_amdgcn_sad_u8(w0 + 2 < g ? p.c[u].z : 0u, 0u, part);
+    part = __builtin_amdgcn_sad_u8(w0 + 3 < g ? p.c[u].w : 0u, 0u, part);
+  }
+  return wave_sum((int)part);
+}
+
+// group_rank_mode in two halves for a 256-thread workgroup: rank_issue<RANK> next to the kernel's first loads (RANK_U8: the
+// byte-table chunks; the other modes issue nothing), rank_finish<RANK> where the flags have arrived.  Same results as
+// group_rank_mode; every thread must call both.
+template <int RANK>
+__device__ __forceinline__ U8Prefix rank_issue(const uint8_t* counts_u8, int64_t g, int tid) {
+  if (RANK == RANK_U8) return u8_prefix_issue(counts_u8, g, tid);
+  return U8Prefix{};
+}
+template <int RANK>
+__device__ __forceinline__ int64_t rank_finish(const U8Prefix& pre, bool flagged, const int32_t* ws, const uint8_t* counts_u8, int64_t G,
+                                               int64_t g, int* lds8, int& k0, int& cnt) {
+  if (RANK != RANK_U8) return group_rank_mode<RANK>(flagged, ws, counts_u8, G, g, lds8, k0, cnt);
+  const int tid = (int)threadIdx.x;
+  const int front = u8_prefix_sum(pre, g, tid);
+  const unsigned long long mask = __ballot(flagged);
+  const int w = tid >> 6;
+  if (lane_id() == 0) {
+    lds8[w] = __popcll(mask);
+    lds8[GROUP_TILES + w] = front;
+  }
+  __syncthreads();
+  int before = 0;
+  k0 = 0;
+  cnt = 0;
+#pragma unroll
+  for (int i = 0; i < GROUP_TILES; ++i) {
+    before += (i < w) ? lds8[i] : 0;
+    cnt += lds8[i];
+    k0 += lds8[GROUP_TILES + i];
+  }
+  return flagged ? (int64_t)k0 + before + rank_below(mask) : -1;
+}
+
 inline int pick_rank(int64_t G, const uint8_t* counts_u8, int64_t int32_max_groups = UNSCANNED_MAX_GROUPS) {
   if (counts_u8 && G <= UNSCANNED_U8_MAX_GROUPS) return RANK_U8;
   return G <= int32_max_groups ? RANK_INT32 : RANK_SCANNED;

@@ -139,9 +139,13 @@ __device__ __forceinline__ float4 quad_dof_draw(const u4 x) {  // torch_rand_flo
   return make_float4(0.4f * u01(x.x) + (-0.2f), 0.4f * u01(x.y) + (-0.2f), 0.4f * u01(x.z) + (-0.2f), 0.4f * u01(x.w) + (-0.2f));
 }
 
-// Order (r02): every load in front of the first store (target and action quads of the lane-linear walk, the env's thrusts and
-// thrust actions, then -- behind the ranks -- the dense lanes' initial rows); the DOF limit rows in LDS (indexed in place by a
-// run-time column they are vector loads of the argument block).  A load issued behind a store waits for that store's round trip.
+// Order (r03): two round trips of loads, neither conditional, both in front of the first store.  Trip 1: the flag (through a
+// clamped index: written as `live && flag[env]` it was a branch around a load with a full wait behind it, a serial round trip
+// in front of everything else), the target and action quads of the lane-linear walk, the env's thrusts and thrust actions.
+// Trip 2, behind the ranks: the dense lanes' initial rows (idle lanes re-read the group's first env).  Then the elementwise
+// stores; the dense lanes' reset rows last, where no other wave waits for their Philox draw (a wave without a dense lane ends
+// before).  The DOF limit rows reach LDS through compile-time indices (indexed by tid they are VECTOR loads of the argument
+// block).  A load issued behind a store waits for that store's round trip.
 template <int RANK>
 __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) {
   __shared__ int lds8[2 * GROUP_TILES];
@@ -155,8 +159,10 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
   const bool live = env < a.n;
   const int64_t envs_here = (a.n - g * GROUP) < GROUP ? (a.n - g * GROUP) : GROUP;
   const int nf4 = (int)(envs_here * QD / 4);
-  // ---- loads
-  const bool flagged = live && a.b.reset_buf[env] != 0;  // :147
+  // ---- trip 1
+  const int64_t le = live ? env : g * GROUP;
+  const int64_t flag_ld = a.b.reset_buf[le];  // :147
+  const U8Prefix rp = rank_issue<RANK>(a.b.tile_counts_u8, g, tid);
   float4 tq[QD / 4], aq[QD / 4];
 #pragma unroll
   for (int it = 0; it < QD / 4; ++it) {
@@ -167,36 +173,35 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
     tq[it] = *reinterpret_cast<const float4*>(a.b.dof_position_targets + i * QD + j0);  // (reset rows read theirs too and ignore it)
     aq[it] = *reinterpret_cast<const float4*>(a.actions_in + i * QA + j0);
   }
-  const int64_t le = live ? env : g * GROUP;
   const float4 th_in = *reinterpret_cast<const float4*>(a.b.thrusts + le * 4);
   float4 ath = *reinterpret_cast<const float4*>(a.actions_in + le * QA + 8);
-  if (tid < QD) {
-    s_lo[tid] = p.dof_lower[tid];
-    s_hi[tid] = p.dof_upper[tid];
+  {
+    float lo = 0.f, hi = 0.f;
+#pragma unroll
+    for (int j = 0; j < QD; ++j) {
+      lo = tid == j ? p.dof_lower[j] : lo;
+      hi = tid == j ? p.dof_upper[j] : hi;
+    }
+    if (tid < QD) {
+      s_lo[tid] = lo;
+      s_hi[tid] = hi;
+    }
   }
+  const bool flagged = live && flag_ld != 0;
   int k0, cnt;  // offset of the group in the id list, flagged envs in the group
-  const int64_t k = group_rank_mode<RANK>(flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
+  const int64_t k = rank_finish<RANK>(rp, flagged, a.b.reset_workspace, a.b.tile_counts_u8, G, g, lds8, k0, cnt);
   if (flagged) s_list[(int)(k - k0)] = tid;
   s_rank[tid] = flagged ? (int)(k - k0) : -1;
   __syncthreads();
-  wait_loads_done();  // (in front of the dense lanes' block: inside it, waves without a dense lane would skip the wait)
+  // ---- trip 2
   const bool dense = tid < cnt;  // dense lanes: thread j takes the group's j-th flagged env
   const int64_t di = g * GROUP + (dense ? s_list[tid] : 0);
-  float ip[3] = {0.f, 0.f, 0.f};
-  float4 iq = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (dense) {
+  float ip[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) ip[c] = a.r.initial_root_pos[di * 3 + c];
-    iq = *reinterpret_cast<const float4*>(a.r.initial_root_rot + di * 4);
-  }
+  for (int c = 0; c < 3; ++c) ip[c] = a.r.initial_root_pos[di * 3 + c];
+  const float4 iq = *reinterpret_cast<const float4*>(a.r.initial_root_rot + di * 4);
 
   // ---- stores
-  if (dense) {
-    const u4 x = quad_block(a, di, 2u);
-    const float u3[3] = {u01(x.x), u01(x.y), u01(x.z)};
-    quad_reset_head(a, di, (int64_t)k0 + tid, u3, ip, iq);
-  }
-
   const float thrust_rate = p.thrust_rate;
   // DOF position targets: lane-linear over the group's 256 x 8 floats; the matching actions are columns 0:8 of a 12-wide row
 #pragma unroll
@@ -252,6 +257,11 @@ __global__ __launch_bounds__(GROUP) void quadcopter_pre_kernel(const QuadPre a) 
     }
   }
   if (g == G - 1 && tid == 0) *a.r.count = (int64_t)k0 + cnt;
+  // ---- the dense lanes' root rows and flags (:209-227)
+  if (!dense) return;
+  const u4 x = quad_block(a, di, 2u);
+  const float u3[3] = {u01(x.x), u01(x.y), u01(x.z)};
+  quad_reset_head(a, di, (int64_t)k0 + tid, u3, ip, iq);
 }
 
 // reset_idx(env_ids) with caller-provided ids and (optionally) pre-drawn U[0,1): one thread per id
