@@ -263,12 +263,117 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
   const bool do_metrics = !SPLIT || (a.stages & OIGE_ANYMAL_STAGE_METRICS);
   const bool do_obs = !SPLIT || (a.stages & OIGE_ANYMAL_STAGE_OBS);
   constexpr bool do_reset = !SPLIT;
-  // ---- A/B: the six 12-wide arrays, lane-linear, into row columns (12 % 4 == 0: a float4 never straddles rows)
+  // The tile's 16 waves per CU are all resident at once (4096 tiles at 256 K envs = the whole grid), so the kernel lasts as
+  // long as ONE wave's chain of memory round trips.  r02's chain had nine links (chunks | scalars, rows, sums | two passes over
+  // each of the two prefix tables | terrain type and origin, behind the reset path's first stores | the new origin, behind more
+  // of them | the actions again for the epilogue, behind all of them | the epilogue's stores); r03's has four:
+  //   trip 0 + 1  pass 0 of the prefix tables, the three 12-wide chunks and the env's own scalars, issued together, nothing
+  //               conditional (dead lanes shadow env0); the tables are summed while the rest is in flight;
+  //   trip 2      behind the frame arithmetic: the env's 12-wide rows, episode sums, terrain level / type / origin;
+  //   trip 3      the new terrain origin of the reset envs (it depends on the level, which depends on the norm), in front of
+  //               the Philox draws and of every store of the reset path;
+  // every store behind the last load, except the three action-column stores, which leave in front of trip 2 (a load issued
+  // behind a store waits for that store's acknowledgement too -- one in-order counter -- and these are acknowledged by then).
+  const bool live = FULLTILE || tid < nv;
+  const int64_t env = live ? env0 + tid : env0;  // dead lanes shadow env0, never store
+  float* row = rows + tid * ARW;
+  // ---- trip 0: pass 0 of the two tables the reset path sums (tile-count bytes of the groups in front of this one, per-group
+  // partial sums of the command norm: what the scan / norm launch would have left; L2 hits, written by the flags kernel).
+  // First of all, when no register is taken yet; summed while trip 1 is in flight.  Two 16-byte chunks of each per lane
+  // cover 512 groups; the rest, if any, in the loop below.
+  constexpr int PU = 2;
+  const int64_t grp = t / GROUP_TILES, NG = num_groups(a.n);
+  const bool own_prefix = do_reset && a.unscanned;  // (uniform)
+  const int64_t nq_u = (grp + 3) / 4, nq_g = NG / 4;  // 16-byte chunks of the byte table in front of the group / of the partial sums
+  const float* gp = reinterpret_cast<const float*>(a.b.reset_workspace + padded_tiles(a.n));  // one partial sum per group
+  uint4 pu[PU];
+  float4 pg[PU];
+  float gtail = 0.f;
+  if (own_prefix) {
+    const uint4* c4 = reinterpret_cast<const uint4*>(a.b.tile_counts_u8);
+    // (fewer than four groups: no whole chunk of sums; the idle slots then re-read the byte table, always 16 bytes at least)
+    const float4* gp4 = nq_g > 0 ? reinterpret_cast<const float4*>(gp) : reinterpret_cast<const float4*>(a.b.tile_counts_u8);
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {  // idle slots re-read a valid chunk
+      const int64_t j = lane_id() + u * WAVE;
+      pu[u] = c4[j < nq_u ? j : (nq_u > 0 ? nq_u - 1 : 0)];
+      pg[u] = gp4[j < nq_g ? j : (nq_g > 0 ? nq_g - 1 : 0)];
+    }
+    const int64_t jt = 4 * nq_g + lane_id();
+    gtail = gp[jt < NG ? jt : 0];
+  }
+
+  // ---- trip 1
+  Chunk<AD> c0, c1, c2;
   if (step) {
-    Chunk<AD> c0, c1, c2;
     load_chunk<AD, FULLTILE>(c0, a.s.dof_pos + env0 * AD, nv * AD);
     load_chunk<AD, FULLTILE>(c1, a.s.dof_vel + env0 * AD, nv * AD);
     load_chunk<AD, FULLTILE>(c2, a.b.actions + env0 * AD, nv * AD);
+  }
+  const float* bp3 = a.s.base_pos + env * 3;
+  f3 bpos{bp3[0], bp3[1], bp3[2]};
+  const float4 q4v = *reinterpret_cast<const float4*>(a.s.base_quat + env * 4);
+  q4 bq{q4v.x, q4v.y, q4v.z, q4v.w};
+  float2 v0 = make_float2(0.f, 0.f), v1 = v0, v2 = v0;
+  if (step) {  // reset_idx(env_ids) on its own reads no velocities
+    const float2* vp = reinterpret_cast<const float2*>(a.s.base_velocities + env * 6);
+    v0 = vp[0]; v1 = vp[1]; v2 = vp[2];
+  }
+  const float4 cm = *reinterpret_cast<const float4*>(a.b.commands + env * 4);
+  float cmd[4] = {cm.x, cm.y, cm.z, cm.w};
+  const int flag_ld = step ? (int)a.b.reset_buf[env] : (int)a.r.reset_mask[env];
+  const int fallen_ld = step ? (int)a.b.has_fallen[env] : 0;
+  const int64_t timeout = step ? a.b.timeout_buf[env] : 0;
+  int64_t k_front = 0;   // flagged envs in front of this tile's group
+  float gnorm_own = 0.f;  // whole-matrix norm of the reset envs' xy commands (:376)
+  if (own_prefix) {  // (uniform) the additions in the order the scan-free path has always taken them: chunk by chunk per lane
+    const int64_t g = grp;
+    unsigned fr = 0;
+    double acc = 0.0;
+    auto add_u = [&](const uint4 c, int64_t j) {
+      const int64_t w0 = 4 * j;  // first word of the chunk; words >= g belong to this group or later ones
+      fr = __builtin_amdgcn_sad_u8(w0 < g ? c.x : 0u, 0u, fr);
+      fr = __builtin_amdgcn_sad_u8(w0 + 1 < g ? c.y : 0u, 0u, fr);
+      fr = __builtin_amdgcn_sad_u8(w0 + 2 < g ? c.z : 0u, 0u, fr);
+      fr = __builtin_amdgcn_sad_u8(w0 + 3 < g ? c.w : 0u, 0u, fr);
+    };
+#pragma unroll
+    for (int u = 0; u < PU; ++u) {
+      const int64_t j = lane_id() + u * WAVE;
+      add_u(pu[u], j);
+      if (j < nq_g) acc += ((double)pg[u].x + (double)pg[u].y) + ((double)pg[u].z + (double)pg[u].w);
+    }
+    const uint4* c4 = reinterpret_cast<const uint4*>(a.b.tile_counts_u8);
+    const float4* gp4 = reinterpret_cast<const float4*>(gp);
+    const int64_t nq_max = nq_u > nq_g ? nq_u : nq_g;
+    for (int64_t j0 = lane_id() + PU * WAVE; j0 < nq_max; j0 += PU * WAVE) {  // more than 512 groups
+      uint4 cu[PU];
+      float4 cg[PU];
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int64_t j = j0 + u * WAVE;
+        cu[u] = c4[j < nq_u ? j : nq_u - 1];
+        cg[u] = gp4[j < nq_g ? j : nq_g - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < PU; ++u) {
+        const int64_t j = j0 + u * WAVE;
+        if (j < nq_u) add_u(cu[u], j);
+        if (j < nq_g) acc += ((double)cg[u].x + (double)cg[u].y) + ((double)cg[u].z + (double)cg[u].w);
+      }
+    }
+    acc += 4 * nq_g + lane_id() < NG ? (double)gtail : 0.0;
+    int front = (int)fr;
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) {
+      front += __shfl_xor(front, off, WAVE);
+      acc += __shfl_xor(acc, off, WAVE);
+    }
+    k_front = front;
+    gnorm_own = __builtin_sqrtf((float)acc);
+  }
+  // ---- the three chunks -> row columns (12 % 4 == 0: a float4 never straddles rows)
+  if (step) {
     scatter_chunk<AD, ARW, L_DPOS, false>(c0, rows, 1.0f);
     scatter_chunk<AD, ARW, L_DVEL, false>(c1, rows, 1.0f);
     scatter_chunk<AD, ARW, L_ACT, false>(c2, rows, 1.0f);
@@ -280,26 +385,23 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
   }
   __syncthreads();
 
+  // The action columns of the observation (176:188) are a copy of `actions` (their noise scale is zero, :170: obs +
+  // (2u - 1) * 0 is obs, no draw): written from the chunk's registers right here (r02 read the actions again for this, behind
+  // the reset path's stores).  Trip 2 is issued behind these three stores: they are acknowledged about when its loads return.
+  if (step && do_obs) {
+#pragma unroll
+    for (int it = 0; it < Chunk<AD>::ITERS; ++it) {  // 12 % 4 == 0: a float4 of the run never straddles two envs
+      const int f = it * WAVE + tid;
+      const int e = f / 3, c = f - 3 * e;
+      if (!FULLTILE && e >= nv) continue;
+      ANYMAL_HEAD_ST4(a.b.obs_buf + (env0 + e) * AO + 176 + 4 * c, c2.v[it]);
+    }
+  }
   // ---- C: per-env math, one env per lane
   {
-    const bool live = FULLTILE || tid < nv;
-    const int64_t env = live ? env0 + tid : env0;  // dead lanes shadow env0, never store
-    float* row = rows + tid * ARW;
-    const float* bp3 = a.s.base_pos + env * 3;
-    f3 bpos{bp3[0], bp3[1], bp3[2]};
-    const float4 q4v = *reinterpret_cast<const float4*>(a.s.base_quat + env * 4);
-    q4 bq{q4v.x, q4v.y, q4v.z, q4v.w};
-    float2 v0 = make_float2(0.f, 0.f), v1 = v0, v2 = v0;
-    if (step) {  // reset_idx(env_ids) on its own reads no velocities
-      const float2* vp = reinterpret_cast<const float2*>(a.s.base_velocities + env * 6);
-      v0 = vp[0]; v1 = vp[1]; v2 = vp[2];
-    }
-    const float4 cm = *reinterpret_cast<const float4*>(a.b.commands + env * 4);
-    float cmd[4] = {cm.x, cm.y, cm.z, cm.w};
-    const bool flagged = live && (step ? a.b.reset_buf[env] : a.r.reset_mask[env]) != 0;  // reset_buf, as the reward reads it
-    const bool reset = do_reset && flagged;                                                // ... and as the in-step reset does
-    const bool has_fallen = step && a.b.has_fallen[env] != 0;
-    const int64_t timeout = step ? a.b.timeout_buf[env] : 0;
+    const bool flagged = live && flag_ld != 0;  // reset_buf, as the reward reads it
+    const bool reset = do_reset && flagged;     // ... and as the in-step reset does
+    const bool has_fallen = step && fallen_ld != 0;
 
     // frame quantities (:422-427)
     f3 lin, ang, grav;
@@ -311,14 +413,6 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
       const float heading = atan2f(fwd.y, fwd.x);
       const float w = 0.5f * wrap_to_pi(cmd[3] - heading);
       if (step) cmd[2] = (w != w) ? w : (w < -1.0f ? -1.0f : (w > 1.0f ? 1.0f : w));
-      if (a.x.base_lin_vel && live) {  // the reference keeps them as attributes (:422-424)
-        float* o0 = a.x.base_lin_vel + env * 3;
-        float* o1 = a.x.base_ang_vel + env * 3;
-        float* o2 = a.x.projected_gravity + env * 3;
-        o0[0] = lin.x; o0[1] = lin.y; o0[2] = lin.z;
-        o1[0] = ang.x; o1[1] = ang.y; o1[2] = ang.z;
-        o2[0] = grav.x; o2[1] = grav.y; o2[2] = grav.z;
-      }
     } else {  // a later stage on its own reads what the FRAME stage left (calculate_metrics / get_observations use the attributes)
       const float* i0 = a.x.base_lin_vel + env * 3;
       const float* i1 = a.x.base_ang_vel + env * 3;
@@ -326,6 +420,45 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
       lin = f3{i0[0], i0[1], i0[2]};
       ang = f3{i1[0], i1[1], i1[2]};
       grav = f3{i2[0], i2[1], i2[2]};
+    }
+
+    // ---- trip 2 (behind the frame arithmetic, which needs trip 1 alone: issued in front of it, the two trips' registers and
+    // the quaternion products' temporaries together are 167 VGPRs, 2 waves per SIMD instead of 4): the env's own 12-wide rows
+    // (they only feed three sums), its episode sums, terrain level / type / origin, and pass 0 of the two tables the reset path
+    // sums (tile-count bytes of the groups in front of this one, per-group partial sums of the command norm: what the scan /
+    // norm launch would have left; L2 hits).  Two 16-byte chunks of each per lane cover 512 groups; the rest, if any, is
+    // fetched where pass 0 is consumed, behind the metrics.
+    float4 tq3[AD / 4], ldv3[AD / 4], la3[AD / 4];
+    if (step) {
+      const float4* tq_row = reinterpret_cast<const float4*>(a.b.torques + env * AD);
+      const float4* ldv_row = reinterpret_cast<const float4*>(a.b.last_dof_vel + env * AD);
+      const float4* la_row = reinterpret_cast<const float4*>(a.b.last_actions + env * AD);
+#pragma unroll
+      for (int g = 0; g < AD / 4; ++g) { tq3[g] = tq_row[g]; ldv3[g] = ldv_row[g]; la3[g] = la_row[g]; }
+    }
+    float es[AE];
+    if (do_metrics || do_reset) {
+#pragma unroll
+      for (int k = 0; k < AE; ++k) es[k] = a.b.episode_sums[(int64_t)k * a.n + env];
+    } else {
+#pragma unroll
+      for (int k = 0; k < AE; ++k) es[k] = 0.f;
+    }
+    int64_t level = a.b.terrain_levels[env];
+    int64_t ttype = 0;
+    f3 origin{0.f, 0.f, 0.f};
+    if (do_reset) {
+      ttype = a.b.terrain_types[env];
+      origin = f3{a.b.env_origins[env * 3], a.b.env_origins[env * 3 + 1], a.b.env_origins[env * 3 + 2]};
+    }
+
+    if (do_frame && a.x.base_lin_vel && live) {  // the reference keeps them as attributes (:422-424)
+      float* o0 = a.x.base_lin_vel + env * 3;
+      float* o1 = a.x.base_ang_vel + env * 3;
+      float* o2 = a.x.projected_gravity + env * 3;
+      o0[0] = lin.x; o0[1] = lin.y; o0[2] = lin.z;
+      o1[0] = ang.x; o1[1] = ang.y; o1[2] = ang.z;
+      o2[0] = grav.x; o2[1] = grav.y; o2[2] = grav.z;
     }
 
     // calculate_metrics (:468-533)
@@ -343,12 +476,6 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
     const float rew_base_height = (bh * bh) * rs[OIGE_AR_BASE_HEIGHT];
     float s_tq = 0.f, s_acc = 0.f, s_rate = 0.f, s_hip = 0.f;
     if (step) {  // the 12-wide sums, four columns at a time (sequential order j = 0..11)
-      const float4* tq_row = reinterpret_cast<const float4*>(a.b.torques + env * AD);
-      const float4* ldv_row = reinterpret_cast<const float4*>(a.b.last_dof_vel + env * AD);
-      const float4* la_row = reinterpret_cast<const float4*>(a.b.last_actions + env * AD);
-      float4 tq3[3], ldv3[3], la3[3];
-#pragma unroll
-      for (int g = 0; g < AD / 4; ++g) { tq3[g] = tq_row[g]; ldv3[g] = ldv_row[g]; la3[g] = la_row[g]; }
 #pragma unroll
       for (int g = 0; g < AD / 4; ++g) {
         const float4 tq = tq3[g], ldv = ldv3[g], dv = lds4(row + L_DVEL + 4 * g);
@@ -393,66 +520,38 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
     rew += (rs[OIGE_AR_TERMINATION] * (flagged ? 1.0f : 0.0f)) * (float)(~timeout);
 
     // episode sums (:524-533); dict order :68-82 -> row index
-    float es[AE];
-    if (live && (do_metrics || do_reset)) {
-#pragma unroll
-      for (int k = 0; k < AE; ++k) es[k] = a.b.episode_sums[(int64_t)k * a.n + env];
-      if (step && do_metrics) {
-        es[0] += rew_lin_vel_xy; es[2] += rew_ang_vel_z; es[1] += rew_lin_vel_z; es[3] += rew_ang_vel_xy;
-        es[4] += rew_orient; es[5] += rew_torque; es[6] += rew_joint_acc; es[11] += rew_action_rate;
-        es[7] += rew_base_height; es[12] += rew_hip;
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < AE; ++k) es[k] = 0.f;
+    if (step && do_metrics) {
+      es[0] += rew_lin_vel_xy; es[2] += rew_ang_vel_z; es[1] += rew_lin_vel_z; es[3] += rew_ang_vel_xy;
+      es[4] += rew_orient; es[5] += rew_torque; es[6] += rew_joint_acc; es[11] += rew_action_rate;
+      es[7] += rew_base_height; es[12] += rew_hip;
     }
 
     // in-step reset (:433-435 -> reset_idx :318-367)
     const unsigned long long rmask = __ballot(reset);
-    int64_t level = live ? a.b.terrain_levels[env] : 0;
+    if (!live) level = 0;
     q4 hq = bq;       // pose the height scan sees
     f3 hpos = bpos;
-    int64_t k_front = 0;   // flagged envs in front of this tile's group
-    float gnorm_own = 0.f;  // whole-matrix norm of the reset envs' xy commands (:376)
     const bool last_tile = t == T - 1;
-    if (do_reset && a.unscanned && (rmask != 0 || last_tile)) {  // (wave-uniform) what the scan / norm launch would have left
-      const int64_t g = t / GROUP_TILES, G = num_groups(a.n);
-      int front = (int)u8_words_partial<WAVE, 2>(a.b.tile_counts_u8, g, lane_id());  // (two chunks in flight: the kernel sits at 124 VGPRs)
-      const float* gp = reinterpret_cast<const float*>(a.b.reset_workspace + padded_tiles(a.n));  // one partial sum per group
-      double acc = 0.0;
-      {  // 16-byte chunks (the slots start at a multiple of four ints: 16-byte aligned), the G % 4 tail by its own lanes
-        const float4* gp4 = reinterpret_cast<const float4*>(gp);
-        const int64_t nq = G / 4;
-        constexpr int U = 2;
-        for (int64_t j0 = lane_id(); j0 < nq; j0 += (int64_t)U * WAVE) {
-          float4 v[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int64_t j = j0 + (int64_t)u * WAVE;
-            v[u] = gp4[j < nq ? j : nq - 1];
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-            if (j0 + (int64_t)u * WAVE < nq) acc += ((double)v[u].x + (double)v[u].y) + ((double)v[u].z + (double)v[u].w);
-        }
-        const int64_t jt = 4 * nq + lane_id();
-        const float tail = gp[jt < G ? jt : 0];
-        acc += jt < G ? (double)tail : 0.0;
-      }
-#pragma unroll
-      for (int off = WAVE / 2; off > 0; off >>= 1) {
-        front += __shfl_xor(front, off, WAVE);
-        acc += __shfl_xor(acc, off, WAVE);
-      }
-      k_front = front;
-      gnorm_own = __builtin_sqrtf((float)acc);
-      if (last_tile && lane_id() == 0) {  // the total, where the scan leaves it (anymal_extras_body reads it)
-        int total = front;
-        for (int64_t tt = g * GROUP_TILES; tt <= t; ++tt) total += tt < t ? a.b.reset_workspace[tt] : __popcll(rmask);
-        a.b.reset_workspace[padded_tiles(a.n) + G] = total;
-      }
+    if (own_prefix && last_tile && lane_id() == 0) {  // the total, where the scan leaves it (anymal_extras_body reads it)
+      int total = (int)k_front;
+      for (int64_t tt = grp * GROUP_TILES; tt <= t; ++tt) total += tt < t ? a.b.reset_workspace[tt] : __popcll(rmask);
+      a.b.reset_workspace[padded_tiles(a.n) + NG] = total;
     }
     if (reset) {
+      // ---- trip 3: update_terrain_level (:369-380) and the origin of the new level, fetched in front of the Philox draws and
+      // of every store of the reset path (r02 fetched it, and the type and the old origin, between those stores).  32-bit
+      // arithmetic: a level is below env_rows (the 64-bit remainder is a hundred instructions and a dozen registers)
+      if (p.init_done && p.curriculum) {
+        const float gnorm = a.unscanned ? gnorm_own : a.b.reduce_workspace[T * RW + 0];
+        const float dist = norm3(f3{bpos.x - origin.x, bpos.y - origin.y, 0.0f});
+        int lv = (int)level;
+        lv -= dist < (gnorm * p.max_episode_length_s) * 0.25f ? 1 : 0;
+        lv += dist > p.half_env_length ? 1 : 0;
+        lv = (lv < 0 ? 0 : lv) % p.env_rows;
+        level = lv;
+        const float* to = a.s.terrain_origins + (lv * p.env_cols + (int)ttype) * 3;
+        origin = f3{to[0], to[1], to[2]};
+      }
       const int64_t g = t / GROUP_TILES;
       const int32_t* tile_counts = a.b.reset_workspace;
       const int32_t* group_offsets = a.b.reset_workspace + padded_tiles(a.n);
@@ -503,16 +602,7 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
       float u6[4], u7[4];
       draw4(6, u6);
       draw4(7, u7);
-      const int64_t type = a.b.terrain_types[env];
-      f3 origin{a.b.env_origins[env * 3], a.b.env_origins[env * 3 + 1], a.b.env_origins[env * 3 + 2]};
-      if (p.init_done && p.curriculum) {  // update_terrain_level :369-380
-        const float gnorm = a.unscanned ? gnorm_own : a.b.reduce_workspace[T * RW + 0];
-        const float dist = norm3(f3{bpos.x - origin.x, bpos.y - origin.y, 0.0f});
-        level -= dist < (gnorm * p.max_episode_length_s) * 0.25f ? 1 : 0;
-        level += dist > p.half_env_length ? 1 : 0;
-        level = (level < 0 ? 0 : level) % p.env_rows;
-        const float* to = a.s.terrain_origins + (level * p.env_cols + type) * 3;
-        origin = f3{to[0], to[1], to[2]};
+      if (p.init_done && p.curriculum) {  // update_terrain_level :369-380 (computed above)
         a.b.terrain_levels[env] = level;
         a.b.env_origins[env * 3] = origin.x; a.b.env_origins[env * 3 + 1] = origin.y; a.b.env_origins[env * 3 + 2] = origin.z;
       }
@@ -605,14 +695,9 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
     }
   }
   if (!step || !do_obs) return;  // uniform across the workgroup
-  // The action columns of the observation (176:188) are a copy of `actions` (their noise scale is zero, :170: obs +
-  // (2u - 1) * 0 is obs, no draw).  The tile's actions are fetched again here, lane-linear and L2-hot, BEFORE the epilogue's
-  // first store: a load issued after a store waits for that store's round trip (loads and stores share vmcnt).
-  Chunk<AD> c_act;
-  load_chunk<AD, FULLTILE>(c_act, a.b.actions + env0 * AD, nv * AD);
   __syncthreads();
 
-  // ---- D1: head (cols 0:36) of every row -> obs_buf with its noise; then the action columns
+  // ---- D1: head (cols 0:36) of every row -> obs_buf with its noise
   {
     constexpr int HF4 = TILE * 9;  // 9 float4 per env
 #pragma unroll
@@ -637,32 +722,40 @@ __device__ __forceinline__ void anymal_head_tile(const AnymalPost& a, float* __r
 #endif
       ANYMAL_HEAD_ST4(a.b.obs_buf + off, v);
     }
-#pragma unroll
-    for (int it = 0; it < Chunk<AD>::ITERS; ++it) {  // 12 % 4 == 0: a float4 of the run never straddles two envs
-      const int f = it * WAVE + tid;
-      const int e = f / 3, c = f - 3 * e;
-      if (!FULLTILE && e >= nv) continue;
-      ANYMAL_HEAD_ST4(a.b.obs_buf + (env0 + e) * AO + 176 + 4 * c, c_act.v[it]);
-    }
   }
 }
 
-__global__ __launch_bounds__(WAVE) void anymal_head_kernel(const AnymalPost a) {
+// One kernel per (NOISE_IN, SPLIT) pair, picked by the host: the registers of the step's own kernel (Philox noise, fused) are
+// then not set by the replay / stage variants (as branches of one kernel they took it from 112 to 158 VGPRs).
+// Four waves per SIMD = 16 one-wave workgroups per CU = every tile of 256 K envs resident at once (9.4 KB of LDS each).  Left to
+// itself the fused kernel takes 151 VGPRs (three waves per SIMD: 56 us); held to 128 it spills ten dwords per lane and runs in
+// 49.6 us (r02, with its nine-trip chain: 112 VGPRs, 51.6 us).  -DOIGE_ANYMAL_HEAD_FREE_VGPRS: the A/B build
+#ifndef OIGE_ANYMAL_HEAD_FREE_VGPRS
+#define HEAD_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define HEAD_OCC
+#endif
+template <bool NOISE_IN, bool SPLIT>
+__global__ __launch_bounds__(WAVE) HEAD_OCC void anymal_head_kernel(const AnymalPost a) {
   __shared__ __align__(16) float lds[TILE * ARW + 48];  // rows + noise scales by column
   const int64_t t = blockIdx.x;
   const int64_t left = a.n - t * TILE;
-  const bool noise_in = a.r.noise_u != nullptr;
-  if (a.stages != 0) {  // individually called stages: one generic instantiation, off the hot path
-    if (noise_in) anymal_head_tile<false, true, true>(a, lds, t, left >= TILE ? TILE : (int)left);
-    else anymal_head_tile<false, false, true>(a, lds, t, left >= TILE ? TILE : (int)left);
+  if (SPLIT) {  // individually called stages: one generic instantiation, off the hot path
+    anymal_head_tile<false, NOISE_IN, true>(a, lds, t, left >= TILE ? TILE : (int)left);
     return;
   }
-  if (left >= TILE) {
-    if (noise_in) anymal_head_tile<true, true>(a, lds, t, TILE);
-    else anymal_head_tile<true, false>(a, lds, t, TILE);
+  if (left >= TILE) anymal_head_tile<true, NOISE_IN>(a, lds, t, TILE);
+  else anymal_head_tile<false, NOISE_IN>(a, lds, t, (int)left);
+}
+
+static void launch_anymal_head(const AnymalPost& a, int64_t T, hipStream_t st) {
+  const bool noise_in = a.r.noise_u != nullptr;
+  if (a.stages != 0) {
+    if (noise_in) hipLaunchKernelGGL((anymal_head_kernel<true, true>), dim3((unsigned)T), dim3(WAVE), 0, st, a);
+    else hipLaunchKernelGGL((anymal_head_kernel<false, true>), dim3((unsigned)T), dim3(WAVE), 0, st, a);
   } else {
-    if (noise_in) anymal_head_tile<false, true>(a, lds, t, (int)left);
-    else anymal_head_tile<false, false>(a, lds, t, (int)left);
+    if (noise_in) hipLaunchKernelGGL((anymal_head_kernel<true, false>), dim3((unsigned)T), dim3(WAVE), 0, st, a);
+    else hipLaunchKernelGGL((anymal_head_kernel<false, false>), dim3((unsigned)T), dim3(WAVE), 0, st, a);
   }
 }
 
@@ -725,13 +818,27 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
   }
   {
     constexpr int ENTRIES = TILE * 25;  // 24 table entries + the position record per env
+    constexpr int EIT = (ENTRIES + ANT - 1) / ANT;
+    // every pose record this thread needs, fetched in one go through clamped indices (r03: inside the loop below each was a
+    // conditional load with a full wait behind it -- seven serial round trips to the records the head kernel has just written,
+    // on another XCD as often as not, in front of every workgroup's scan)
+    float4 qs[EIT];
+    float zs[EIT];
 #pragma unroll
-    for (int it = 0; it < (ENTRIES + ANT - 1) / ANT; ++it) {
+    for (int it = 0; it < EIT; ++it) {
+      const int i = it * ANT + tid;
+      int e = (i < ENTRIES ? i : ENTRIES - 1) / 25;
+      if (!FULLTILE) e = e < nv ? e : nv - 1;
+      qs[it] = *reinterpret_cast<const float4*>(pose_in + e * APOSE);  // w, z, x, y
+      zs[it] = pose_in[e * APOSE + 4];
+    }
+#pragma unroll
+    for (int it = 0; it < EIT; ++it) {
       const int i = it * ANT + tid;
       if (i >= ENTRIES) continue;
       const int e = i / 25, j = i - 25 * e;
       if (!FULLTILE && e >= nv) continue;
-      const float4 q = *reinterpret_cast<const float4*>(pose_in + e * APOSE);  // w, z, x, y (L2-hot: just written)
+      const float4 q = qs[it];
       if (j < 10) {
         const float hy = 0.1f * (float)(j < 5 ? j - 5 : j - 4);
         const float tx = -((q.y * hy) * 2.0f);
@@ -742,7 +849,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
         const float ty = (q.y * hx) * 2.0f;
         *reinterpret_cast<float2*>(s_env + e * AER + 2 * j) = make_float2(q.y * ty, q.x * ty);
       } else {
-        *reinterpret_cast<float4*>(s_env + e * AER + AE_POS) = make_float4(q.z, q.w, pose_in[e * APOSE + 4], 0.f);
+        *reinterpret_cast<float4*>(s_env + e * AER + AE_POS) = make_float4(q.z, q.w, zs[it], 0.f);
       }
     }
   }
@@ -813,6 +920,10 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
       idx[g] = __mul24(px, hs_cols) + py;  // both below 2^24: v_mad_i32_i24 is full rate, v_mul_lo_u32 quarter rate
     }
     int16_t h1[ANG], h2[ANG];
+    // every gather of the chunk leaves before the first is consumed: without the fences the scheduler interleaves the last
+    // pass's index arithmetic with the first passes' conversions and puts a full wait in front of the last gather (two exposed
+    // round trips per chunk instead of one; r03)
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < ANG; ++g) {
 #if defined(OIGE_EXP_SCAN_NOGATHER)
@@ -831,6 +942,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
       }
 #endif
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < ANG; ++g) {
       const float mh = (float)(h1[g] < h2[g] ? h1[g] : h2[g]) * p.vertical_scale;
@@ -1085,7 +1197,7 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
     }
     if (head_split) {
       if (stages & OIGE_ANYMAL_STAGE_OBS) a.p.add_noise = 0;  // get_observations adds none (:535-552); :438-439 is the caller's line
-      hipLaunchKernelGGL(anymal_head_kernel, dim3((unsigned)T), dim3(WAVE), 0, st, a);
+      launch_anymal_head(a, T, st);
       if (int rc = check_launch("anymal_head_kernel")) return rc;
       if (stages & OIGE_ANYMAL_STAGE_OBS) {
         hipLaunchKernelGGL(anymal_scan_kernel, dim3((unsigned)T + 1), dim3(ANT), 0, st, a);
@@ -1101,7 +1213,7 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
                        b.reduce_workspace, T);
     if (int rc = check_launch("anymal_scan_norm_kernel")) return rc;
   }
-  hipLaunchKernelGGL(anymal_head_kernel, dim3((unsigned)T), dim3(WAVE), 0, st, a);
+  launch_anymal_head(a, T, st);
   if (int rc = check_launch("anymal_head_kernel")) return rc;
   if (mode == 0) {  // T scan workgroups + one that folds the extras
     hipLaunchKernelGGL(anymal_scan_kernel, dim3((unsigned)T + 1), dim3(ANT), 0, st, a);
