@@ -46,8 +46,13 @@ class CartpoleTask(RLTask):
     def initialize_views(self, scene=None):
         self.set_up_scene(scene)
 
-    # ------------------------------------------------------------------ C-ABI argument blocks
+    # ------------------------------------------------------------------ C-ABI argument blocks (cached: RLTask._block)
     def _params(self) -> _lib.CartpoleParams:
+        sc = (self._cart_dof_idx, self._pole_dof_idx, self._cartpoles.num_dof, self._reset_dist, self._max_push_effort,
+              self._max_episode_length)
+        return self._block("params", (), sc, self._build_params)
+
+    def _build_params(self) -> _lib.CartpoleParams:
         p = _lib.CartpoleParams()
         p.cart_dof_idx, p.pole_dof_idx, p.num_dof = self._cart_dof_idx, self._pole_dof_idx, self._cartpoles.num_dof
         p.reset_dist, p.max_push_effort = self._reset_dist, self._max_push_effort
@@ -55,6 +60,10 @@ class CartpoleTask(RLTask):
         return p
 
     def _buffers(self) -> _lib.CartpoleBuffers:
+        ts = (self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf, self._reset_workspace)
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.CartpoleBuffers:
         n = self._num_envs
         rq = _lib.require_device_tensor
         rq(self.obs_buf, torch.float32, (n, 4), "obs_buf")
@@ -67,15 +76,20 @@ class CartpoleTask(RLTask):
         b.reset_workspace = self._reset_workspace.data_ptr()
         return b
 
-    def _post(self, stages: int) -> None:
+    def _checked_state(self, dof_pos, dof_vel):
         n, d = self._num_envs, self._cartpoles.num_dof
-        dof_pos = self._cartpoles.get_joint_positions(clone=False)
-        dof_vel = self._cartpoles.get_joint_velocities(clone=False)
         _lib.require_device_tensor(dof_pos, torch.float32, (n, d), "dof_pos")
         _lib.require_device_tensor(dof_vel, torch.float32, (n, d), "dof_vel")
+        return dof_pos.data_ptr(), dof_vel.data_ptr()
+
+    def _post(self, stages: int) -> None:
+        n = self._num_envs
+        dof_pos = self._cartpoles.get_joint_positions(clone=False)
+        dof_vel = self._cartpoles.get_joint_velocities(clone=False)
+        pos_ptr, vel_ptr = self._block("state", (dof_pos, dof_vel), (), lambda: self._checked_state(dof_pos, dof_vel))
         p, b = self._params(), self._buffers()
         rc = _lib.load().oige_cartpole_post_physics(
-            C.byref(p), dof_pos.data_ptr(), dof_vel.data_ptr(), C.byref(b), n, stages,
+            C.byref(p), pos_ptr, vel_ptr, C.byref(b), n, stages,
             _lib.current_stream(self.obs_buf.device),
         )
         _lib.check(rc, "oige_cartpole_post_physics")
@@ -106,23 +120,33 @@ class CartpoleTask(RLTask):
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def _reset_io(self, u=None) -> _lib.CartpoleResetIO:
+        o = self._reset_out
+        ts = (u, o["env_ids"], o["count"], o["dof_pos"], o["dof_vel"], self._step_dev if self._capturing else None)
+        r = self._block("reset_io", ts, (self._rand_seed,), lambda: self._build_reset_io(u))
+        r.step = self._step_count  # the one field that changes from step to step
+        return r
+
+    def _build_reset_io(self, u) -> _lib.CartpoleResetIO:
         r = _lib.CartpoleResetIO()
         if u is not None:
             r.u = u.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
-        r.step = self._step_count
         r.step_ptr = self._graph_step_ptr()
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
         return r
 
+    def _checked_actions(self, actions):
+        actions = actions.to(self._device)
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, 1), "actions")
+        return actions
+
     def pre_physics_step(self, actions) -> None:
         if not self.world.is_playing():
             return
         n = self._num_envs
-        actions = actions.to(self._device)
-        _lib.require_device_tensor(actions, torch.float32, (n, 1), "actions")
+        actions = self._block("actions_in", (actions,), (), lambda: self._checked_actions(actions))
         self._advance_step_counter()
         flags = 0
         o = self._reset_out
