@@ -1188,10 +1188,14 @@ def main() -> None:
     if not dry and not args.graph and not args.no_graph_leg:
         graph_ms, graph_note = graph_leg(bench, args.steps, dist)
 
-    traffic = traffic_source = None
+    traffic = traffic_source = pre_traffic = None
     if args.traffic_json and os.path.exists(args.traffic_json) and not dry:
         with open(args.traffic_json) as f:
-            rec = json.load(f).get(args.task)
+            recs = json.load(f)
+        rec = recs.get(args.task)
+        pre_rec = recs.get(args.task + ":pre")  # the pre-physics kernels, captured on the default workload
+        if pre_rec and args.reset_frac is None:
+            pre_traffic = pre_rec["hbm_bytes_per_launch"] * n / pre_rec["envs"]
         if rec:  # measured at rec["envs"] envs per launch; the kernels stream, so bytes scale with the env count
             traffic = rec["hbm_bytes_per_launch"] * n / rec["envs"]
             traffic_source = (f"{os.path.relpath(args.traffic_json, ROOT)}: rocprofv3 --pmc 2 x FETCH_SIZE + WRITE_SIZE of {rec.get('kernel', 'the post kernel')}"
@@ -1251,7 +1255,8 @@ def main() -> None:
                 pre_gbs = pb / (pre_ms * 1e-3) / 1e9
                 step_gbs = (pb + bench.post_bytes * n) / (gpu_span_ms * 1e-3) / 1e9
                 out["roofline"]["pre"] = {"what": "everything the step launches before the post kernel (compaction scan, resets, action scaling)",
-                                          "algorithmic_bytes": pb, "ms": pre_ms, "achieved": pre_gbs, "frac": pre_gbs / HBM_PEAK_GBS}
+                                          "algorithmic_bytes": pb, "ms": pre_ms, "achieved": pre_gbs, "frac": pre_gbs / HBM_PEAK_GBS,
+                                          "traffic": pre_traffic}
                 if event_overhead_ms is not None and not args.graph:
                     net_post, net_pre = max(post_ms - event_overhead_ms, 1e-9), max(pre_ms - event_overhead_ms, 1e-9)
                     out["roofline"]["net_of_event_overhead"] = {

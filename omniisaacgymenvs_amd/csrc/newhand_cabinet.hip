@@ -99,6 +99,8 @@ __device__ __forceinline__ void nh_post_tile(const NhPost& a, float* __restrict_
   float* row = tile + lane * FO;
   float action_penalty = 0.0f;
   if (do_metrics) {  // torch.sum(actions ** 2, dim=-1): the env's A actions through the tile
+    // (r03: fetching this chunk and the two below together with the scalars above -- one round trip instead of three -- takes
+    // 185 VGPRs and is no faster: 93.0 against 92.1 us; ten resident one-wave workgroups per CU hide the chain)
     Chunk<A> c_act;
     load_chunk<A, FULL>(c_act, a.b.actions + env0 * A, nv * A);
     scatter_chunk<A, FO, 0, false>(c_act, tile, 1.0f);

@@ -93,6 +93,20 @@ def main() -> None:
         if names:
             traffic[task] = {"kernel": " + ".join(names), "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
                              "hbm_bytes_per_launch": 2.0 * fetch + write, "envs": DEFAULT_ENVS[task]}
+    # the same for the pre-physics kernels (one entry "<Task>:pre" each): every oige kernel of the task's run that is not one of
+    # its post kernels -- the *_pre_kernel, AnymalTerrain's torques kernel, the scan / finalize / extras launches that ride along
+    for task, ks in pmc.items():
+        fetch = write = 0.0
+        names = []
+        for k, cs in ks.items():
+            is_post = any(d in k for d in dominant[task])
+            if not is_post and ("_pre_kernel" in k or "torques" in k) and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                fetch += cs["FETCH_SIZE"]["mean"] * 1024.0
+                write += cs["WRITE_SIZE"]["mean"] * 1024.0
+                names.append(k)
+        if names:
+            traffic[task + ":pre"] = {"kernel": " + ".join(names), "fetch_size_bytes_raw": fetch, "write_size_bytes": write,
+                                      "hbm_bytes_per_launch": 2.0 * fetch + write, "envs": DEFAULT_ENVS[task]}
     json.dump(traffic, open(os.path.join(dst_dir, "traffic.json"), "w"), indent=1)
 
 
