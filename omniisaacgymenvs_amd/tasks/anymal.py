@@ -108,8 +108,15 @@ class AnymalTask(RLTask):
         indices = torch.arange(self._anymals.count, dtype=torch.int64, device=dev)
         self.reset_idx(indices)
 
-    # ------------------------------------------------------------------ C-ABI argument blocks
+    # ------------------------------------------------------------------ C-ABI argument blocks (cached: RLTask._block keys them
+    # on the identity of the tensors they point into and on the value of their scalars)
     def _params(self) -> _lib.AnymalFlatParams:
+        sc = (self.lin_vel_scale, self.ang_vel_scale, self.dof_pos_scale, self.dof_vel_scale, self.action_scale, self.dt,
+              self.clip_actions, self.max_episode_length, *self.rew_scales.values(), *self.command_x_range, *self.command_y_range,
+              *self.command_yaw_range)
+        return self._block("params", (self._host_consts,), sc, self._build_params)
+
+    def _build_params(self) -> _lib.AnymalFlatParams:
         p = _lib.AnymalFlatParams()
         p.lin_vel_scale, p.ang_vel_scale = self.lin_vel_scale, self.ang_vel_scale
         p.dof_pos_scale, p.dof_vel_scale = self.dof_pos_scale, self.dof_vel_scale
@@ -126,6 +133,11 @@ class AnymalTask(RLTask):
         return p
 
     def _buffers(self) -> _lib.AnymalFlatBuffers:
+        ts = (self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf, self.commands, self.actions, self.last_actions,
+              self.last_dof_vel, self.current_targets, self._reset_workspace, self._tile_counts_u8)
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.AnymalFlatBuffers:
         n, rq = self._num_envs, _lib.require_device_tensor
         rq(self.obs_buf, torch.float32, (n, 48), "obs_buf")
         rq(self.rew_buf, torch.float32, (n,), "rew_buf")
@@ -144,11 +156,15 @@ class AnymalTask(RLTask):
         return b
 
     def _state(self) -> _lib.AnymalFlatState:
-        n, rq = self._num_envs, _lib.require_device_tensor
         torso_position, torso_rotation = self._anymals.get_world_poses(clone=False)
         root_velocities = self._anymals.get_velocities(clone=False)
         dof_pos = self._anymals.get_joint_positions(clone=False)
         dof_vel = self._anymals.get_joint_velocities(clone=False)
+        live = (torso_position, torso_rotation, root_velocities, dof_pos, dof_vel)
+        return self._block("state", live, (), lambda: self._build_state(*live))
+
+    def _build_state(self, torso_position, torso_rotation, root_velocities, dof_pos, dof_vel) -> _lib.AnymalFlatState:
+        n, rq = self._num_envs, _lib.require_device_tensor
         rq(torso_position, torch.float32, (n, 3), "torso_position")
         rq(torso_rotation, torch.float32, (n, 4), "torso_rotation")
         rq(root_velocities, torch.float32, (n, 6), "root_velocities")
@@ -189,12 +205,18 @@ class AnymalTask(RLTask):
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def _reset_io(self, u_vel=None, u_cmd=None) -> _lib.AnymalFlatResetIO:
+        ts = (self.initial_root_pos, self.initial_root_rot, u_vel, u_cmd, *self._reset_out.values(),
+              self._step_dev if self._capturing else None)
+        r = self._block("reset_io", ts, (self._rand_seed,), lambda: self._build_reset_io(u_vel, u_cmd))
+        r.step = self._step_count  # the one field that changes from step to step
+        return r
+
+    def _build_reset_io(self, u_vel, u_cmd) -> _lib.AnymalFlatResetIO:
         r = _lib.AnymalFlatResetIO()
         r.initial_root_pos, r.initial_root_rot = self.initial_root_pos.data_ptr(), self.initial_root_rot.data_ptr()
         if u_vel is not None:
             r.u_vel, r.u_cmd = u_vel.data_ptr(), u_cmd.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
-        r.step = self._step_count
         r.step_ptr = self._graph_step_ptr()
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
@@ -213,12 +235,16 @@ class AnymalTask(RLTask):
         self._anymals.set_world_poses(o["root_pos"][sl], o["root_rot"][sl], **kw)
         self._anymals.set_velocities(o["root_vel"][sl], **kw)
 
+    def _checked_actions(self, actions):
+        actions = actions.to(self._device)
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, 12), "actions")
+        return actions
+
     def pre_physics_step(self, actions) -> None:
         if not self.world.is_playing():
             return
         n = self._num_envs
-        actions = actions.to(self._device)
-        _lib.require_device_tensor(actions, torch.float32, (n, 12), "actions")
+        actions = self._block("actions_in", (actions,), (), lambda: self._checked_actions(actions))
         self._advance_step_counter()
         flags = 0
         if not self.sync_free:

@@ -96,8 +96,14 @@ class BallBalanceTask(RLTask):
         self._host_consts = {"lower": self.bbot_dof_lower_limits.tolist(), "upper": self.bbot_dof_upper_limits.tolist(),
                              "actuated": [int(i) for i in self.actuated_dof_indices]}
 
-    # ------------------------------------------------------------------ C-ABI argument blocks
+    # ------------------------------------------------------------------ C-ABI argument blocks (cached: RLTask._block keys them
+    # on the identity of the tensors they point into and on the value of their scalars)
     def _params(self) -> _lib.BallBalanceParams:
+        sc = (self._dt, self._action_speed_scale, self._ball_radius, self.clip_actions, self._max_episode_length,
+              self._balance_bots.num_dof)
+        return self._block("params", (self._host_consts,), sc, self._build_params)
+
+    def _build_params(self) -> _lib.BallBalanceParams:
         p = _lib.BallBalanceParams()
         p.rate = self._dt * self._action_speed_scale  # a Python double product, rounded once (:196-198)
         p.ball_low = self._ball_radius * 1.5           # :305
@@ -112,6 +118,11 @@ class BallBalanceTask(RLTask):
         return p
 
     def _buffers(self) -> _lib.BallBalanceBuffers:
+        ts = (self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf, self.dof_position_targets, self._reset_workspace,
+              self._tile_counts_u8)
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.BallBalanceBuffers:
         n, rq = self._num_envs, _lib.require_device_tensor
         rq(self.obs_buf, torch.float32, (n, 24), "obs_buf")
         rq(self.rew_buf, torch.float32, (n,), "rew_buf")
@@ -126,12 +137,16 @@ class BallBalanceTask(RLTask):
         return b
 
     def _state(self) -> _lib.BallBalanceState:
-        n, d, rq = self._num_envs, self._balance_bots.num_dof, _lib.require_device_tensor
         ball_positions, _ = self._balls.get_world_poses(clone=False)
         ball_velocities = self._balls.get_velocities(clone=False)
         dof_pos = self._balance_bots.get_joint_positions(clone=False)
         dof_vel = self._balance_bots.get_joint_velocities(clone=False)
         sensors = self._balance_bots.get_measured_joint_forces(joint_indices=self._sensor_indices)
+        live = (ball_positions, ball_velocities, dof_pos, dof_vel, sensors)
+        return self._block("state", (*live, self._env_pos), (), lambda: self._build_state(*live))
+
+    def _build_state(self, ball_positions, ball_velocities, dof_pos, dof_vel, sensors) -> _lib.BallBalanceState:
+        n, d, rq = self._num_envs, self._balance_bots.num_dof, _lib.require_device_tensor
         rq(ball_positions, torch.float32, (n, 3), "ball_positions")
         rq(ball_velocities, torch.float32, (n, 6), "ball_velocities")
         rq(dof_pos, torch.float32, (n, d), "dof_pos")
@@ -169,6 +184,13 @@ class BallBalanceTask(RLTask):
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def _reset_io(self, u=None) -> _lib.BallBalanceResetIO:
+        ts = (self.initial_ball_pos, self.initial_bot_pos, self.initial_bot_rot, self.initial_bot_velocities,
+              self.initial_dof_positions, u, *self._reset_out.values(), self._step_dev if self._capturing else None)
+        r = self._block("reset_io", ts, (self._rand_seed,), lambda: self._build_reset_io(u))
+        r.step = self._step_count  # the one field that changes from step to step
+        return r
+
+    def _build_reset_io(self, u) -> _lib.BallBalanceResetIO:
         r = _lib.BallBalanceResetIO()
         r.initial_ball_pos = self.initial_ball_pos.data_ptr()
         r.initial_bot_pos, r.initial_bot_rot = self.initial_bot_pos.data_ptr(), self.initial_bot_rot.data_ptr()
@@ -176,7 +198,6 @@ class BallBalanceTask(RLTask):
         if u is not None:
             r.u = u.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
-        r.step = self._step_count
         r.step_ptr = self._graph_step_ptr()
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
@@ -197,12 +218,16 @@ class BallBalanceTask(RLTask):
         self._balance_bots.set_velocities(o["bot_vel"][sl], **kw)
         self._balance_bots.set_joint_positions(o["dof_pos"][sl], **kw)
 
+    def _checked_actions(self, actions):
+        actions = actions.to(self.device)
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, 3), "actions")
+        return actions
+
     def pre_physics_step(self, actions) -> None:
         if not self.world.is_playing():
             return
         n = self._num_envs
-        actions = actions.to(self.device)
-        _lib.require_device_tensor(actions, torch.float32, (n, 3), "actions")
+        actions = self._block("actions_in", (actions,), (), lambda: self._checked_actions(actions))
         self._advance_step_counter()
         flags, ids = 0, None
         if not self.sync_free:

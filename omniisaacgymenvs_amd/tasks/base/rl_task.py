@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import gc
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -32,6 +33,38 @@ def quiesce_gc() -> bool:
     gc.collect()
     gc.disable()
     return on
+
+
+# OIGE_CHECK_BLOCKS=1 (tests): every cache hit also rebuilds the block and compares it with the cached one, field for field --
+# a dependency missing from a block's key then fails loudly instead of handing the kernels a stale pointer.
+_CHECK_BLOCKS = os.environ.get("OIGE_CHECK_BLOCKS") == "1"
+_VOLATILE_FIELDS = ("step",)  # written by the caller on every call, behind the cache
+
+
+def _assert_same_block(name, cached, fresh) -> None:
+    import ctypes
+
+    if isinstance(cached, ctypes.Structure):
+        for field in cached._fields_:
+            f = field[0]
+            if f in _VOLATILE_FIELDS:
+                continue
+            a, b = getattr(cached, f), getattr(fresh, f)
+            if isinstance(a, ctypes.Array):
+                a, b = bytes(a), bytes(b)
+            elif isinstance(a, ctypes.Structure):
+                _assert_same_block(f"{name}.{f}", a, b)
+                continue
+            if a != b and not (a != a and b != b):
+                raise AssertionError(f"cached argument block '{name}' is stale: field {f} is {a!r}, a fresh build gives {b!r}")
+    elif isinstance(cached, (tuple, list)):
+        for i, (a, b) in enumerate(zip(cached, fresh)):
+            _assert_same_block(f"{name}[{i}]", a, b)
+    elif isinstance(cached, torch.Tensor):
+        if cached is not fresh and cached.data_ptr() != fresh.data_ptr():
+            raise AssertionError(f"cached '{name}' is stale: another tensor")
+    elif cached != fresh:
+        raise AssertionError(f"cached '{name}' is stale: {cached!r} != {fresh!r}")
 
 
 class RLTask:
@@ -247,6 +280,8 @@ class RLTask:
             blocks = self._blocks = {}
         hit = blocks.get(name)
         if hit is not None and hit[0] == key:
+            if _CHECK_BLOCKS:
+                _assert_same_block(name, hit[2], build())
             return hit[2]
         blk = build()
         blocks[name] = (key, tensors, blk)

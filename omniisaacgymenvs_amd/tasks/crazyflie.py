@@ -117,8 +117,13 @@ class CrazyflieTask(RLTask):
         self._noise4 = torch.zeros(4, **f)
         self.set_targets(self.all_indices)
 
-    # ------------------------------------------------------------------ C-ABI argument blocks
+    # ------------------------------------------------------------------ C-ABI argument blocks (cached: RLTask._block keys them
+    # on the identity of the tensors they point into and on the value of their scalars)
     def _params(self) -> _lib.CrazyflieParams:
+        sc = (self.motor_tau_up, self.motor_tau_down, self.prop_max_rot, self.clip_actions, self._max_episode_length)
+        return self._block("params", (self._thrust_max_host,), sc, self._build_params)
+
+    def _build_params(self) -> _lib.CrazyflieParams:
         p = _lib.CrazyflieParams()
         p.motor_tau_up, p.motor_tau_down, p.prop_max_rot = self.motor_tau_up, self.motor_tau_down, self.prop_max_rot
         p.clip_actions = float(min(self.clip_actions, 3.0e38))
@@ -128,6 +133,12 @@ class CrazyflieTask(RLTask):
         return p
 
     def _buffers(self) -> _lib.CrazyflieBuffers:
+        ts = (self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf, self.target_positions, self.thrusts, self.actions,
+              self.thrust_cmds_damp, self.thrust_rot_damp, self.dof_pos, self.dof_vel, self._episode_sums, self._extras_buf,
+              self._reset_workspace, self._target_workspace, self._reduce_workspace)
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.CrazyflieBuffers:
         n, rq = self._num_envs, _lib.require_device_tensor
         rq(self.obs_buf, torch.float32, (n, 18), "obs_buf")
         rq(self.rew_buf, torch.float32, (n,), "rew_buf")
@@ -149,9 +160,12 @@ class CrazyflieTask(RLTask):
         return b
 
     def _state(self) -> _lib.CrazyflieState:
-        n, rq = self._num_envs, _lib.require_device_tensor
         self.root_pos, self.root_rot = self._copters.get_world_poses(clone=False)
         self.root_velocities = self._copters.get_velocities(clone=False)
+        return self._block("state", (self.root_pos, self.root_rot, self.root_velocities, self._env_pos), (), self._build_state)
+
+    def _build_state(self) -> _lib.CrazyflieState:
+        n, rq = self._num_envs, _lib.require_device_tensor
         rq(self.root_pos, torch.float32, (n, 3), "root_pos")
         rq(self.root_rot, torch.float32, (n, 4), "root_rot")
         rq(self.root_velocities, torch.float32, (n, 6), "root_velocities")
@@ -188,6 +202,11 @@ class CrazyflieTask(RLTask):
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def _reset_io(self) -> _lib.CrazyflieResetIO:
+        ts = (self.initial_root_pos, self.initial_root_rot, self.initial_ball_rot, self._env_pos, self._noise4,
+              *self._reset_out.values())
+        return self._block("reset_io", ts, (), self._build_reset_io)
+
+    def _build_reset_io(self) -> _lib.CrazyflieResetIO:
         r = _lib.CrazyflieResetIO()
         r.initial_root_pos, r.initial_root_rot = self.initial_root_pos.data_ptr(), self.initial_root_rot.data_ptr()
         r.initial_ball_rot, r.env_pos = self.initial_ball_rot.data_ptr(), self._env_pos.data_ptr()
@@ -221,12 +240,16 @@ class CrazyflieTask(RLTask):
     def _bind_extras(self) -> None:
         self.extras["episode"] = {k: self._extras_buf[i] for i, k in enumerate(EPISODE_KEYS)}
 
+    def _checked_actions(self, actions):
+        actions = actions.to(self._device)
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, 4), "actions")
+        return actions
+
     def pre_physics_step(self, actions) -> None:
         if not self.world.is_playing():
             return
         n = self._num_envs
-        actions = actions.to(self._device)
-        _lib.require_device_tensor(actions, torch.float32, (n, 4), "actions")
+        actions = self._block("actions_in", (actions,), (), lambda: self._checked_actions(actions))
         flags, ids = 0, None
         if not self.sync_free:
             o = self._reset_out

@@ -195,8 +195,19 @@ class FrankaCabinetTask(RLTask):
         indices = torch.arange(n, dtype=torch.int64, device=dev)
         self.reset_idx(indices)
 
-    # ------------------------------------------------------------------ C-ABI argument blocks
+    # ------------------------------------------------------------------ C-ABI argument blocks (cached: RLTask._block keys them
+    # on the identity of the tensors they point into and on the value of their scalars)
+    _PARAM_SCALARS = ("action_scale", "dof_vel_scale", "dt", "clip_actions", "dist_reward_scale", "rot_reward_scale",
+                      "around_handle_reward_scale", "open_reward_scale", "finger_dist_reward_scale", "action_penalty_scale",
+                      "finger_close_reward_scale", "NUM_DOFS", "REWARD_VARIANT", "OPEN_BONUS_THRESHOLD", "OPEN_DONE_THRESHOLD",
+                      "_max_episode_length", "num_props")
+
     def _params(self) -> _lib.FrankaCabinetParams:
+        d = self.__dict__
+        sc = [d[k] if k in d else getattr(self, k) for k in self._PARAM_SCALARS]
+        return self._block("params", (self._rows_host,), sc, self._build_params)
+
+    def _build_params(self) -> _lib.FrankaCabinetParams:
         p, h = _lib.FrankaCabinetParams(), self._rows_host
         p.action_scale, p.dof_vel_scale, p.dt = self.action_scale, self.dof_vel_scale, self.dt
         p.clip_actions = float(min(self.clip_actions, 3.0e38))
@@ -218,6 +229,12 @@ class FrankaCabinetTask(RLTask):
         return p
 
     def _buffers(self) -> _lib.FrankaCabinetBuffers:
+        ts = (self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf, self.actions, self.franka_dof_targets,
+              self.franka_grasp_rot, self.franka_grasp_pos, self.drawer_grasp_rot, self.drawer_grasp_pos, self._reset_workspace,
+              self._tile_counts_u8)
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.FrankaCabinetBuffers:
         n, rq = self._num_envs, _lib.require_device_tensor
         D = self.NUM_DOFS
         rq(self.obs_buf, torch.float32, (n, 2 * D + 5), "obs_buf")
@@ -237,7 +254,6 @@ class FrankaCabinetTask(RLTask):
         return b
 
     def _state(self) -> _lib.FrankaCabinetState:
-        n, rq = self._num_envs, _lib.require_device_tensor
         hand_pos, hand_rot = self._frankas._hands.get_world_poses(clone=False)
         drawer_pos, drawer_rot = self._cabinets._drawers.get_world_poses(clone=False)
         self.franka_dof_pos = self._frankas.get_joint_positions(clone=False)
@@ -247,6 +263,12 @@ class FrankaCabinetTask(RLTask):
         self.franka_lfinger_pos, self.franka_lfinger_rot = self._frankas._lfingers.get_world_poses(clone=False)
         rview = self._frankas._rfingers if self.use_right_finger_view else self._frankas._lfingers  # :337
         self.franka_rfinger_pos, self.franka_rfinger_rot = rview.get_world_poses(clone=False)
+        live = (hand_pos, hand_rot, drawer_pos, drawer_rot, franka_dof_vel)
+        ts = (*live, self.franka_dof_pos, self.cabinet_dof_pos, self.cabinet_dof_vel, self.franka_lfinger_pos, self.franka_rfinger_pos)
+        return self._block("state", ts, (), lambda: self._build_state(*live))
+
+    def _build_state(self, hand_pos, hand_rot, drawer_pos, drawer_rot, franka_dof_vel) -> _lib.FrankaCabinetState:
+        n, rq = self._num_envs, _lib.require_device_tensor
         for t, w, name in ((hand_pos, 3, "hand_pos"), (hand_rot, 4, "hand_rot"), (drawer_pos, 3, "drawer_pos"), (drawer_rot, 4, "drawer_rot"),
                            (self.franka_dof_pos, self.NUM_DOFS, "franka_dof_pos"), (franka_dof_vel, self.NUM_DOFS, "franka_dof_vel"),
                            (self.cabinet_dof_pos, 4, "cabinet_dof_pos"), (self.cabinet_dof_vel, 4, "cabinet_dof_vel"),
@@ -292,13 +314,19 @@ class FrankaCabinetTask(RLTask):
         raise NotImplementedError("compute_franka_reward runs inside oige_franka_cabinet_post_physics (metrics stage)")
 
     def _reset_io(self, u_dof=None) -> _lib.FrankaCabinetResetIO:
+        props = (self.default_prop_pos, self.default_prop_rot) if self.num_props > 0 else ()
+        ts = (u_dof, *props, *self._reset_out.values(), self._step_dev if self._capturing else None)
+        r = self._block("reset_io", ts, (self._rand_seed, self.num_props), lambda: self._build_reset_io(u_dof))
+        r.step = self._step_count  # the one field that changes from step to step
+        return r
+
+    def _build_reset_io(self, u_dof) -> _lib.FrankaCabinetResetIO:
         r, o = _lib.FrankaCabinetResetIO(), self._reset_out
         if u_dof is not None:
             r.u_dof = u_dof.data_ptr()
         if self.num_props > 0:
             r.default_prop_pos, r.default_prop_rot = self.default_prop_pos.data_ptr(), self.default_prop_rot.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
-        r.step = self._step_count
         r.step_ptr = self._graph_step_ptr()
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
@@ -323,12 +351,16 @@ class FrankaCabinetTask(RLTask):
         self._frankas.set_joint_positions(o["dof_pos"][sl], **kw)
         self._frankas.set_joint_velocities(o["dof_vel"][sl], **kw)
 
+    def _checked_actions(self, actions):
+        actions = actions.to(self._device)
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, self.NUM_DOFS), "actions")
+        return actions
+
     def pre_physics_step(self, actions) -> None:
         if not self.world.is_playing():
             return
         n = self._num_envs
-        actions = actions.to(self._device)
-        _lib.require_device_tensor(actions, torch.float32, (n, self.NUM_DOFS), "actions")
+        actions = self._block("actions_in", (actions,), (), lambda: self._checked_actions(actions))
         self._advance_step_counter()
         flags = 0
         if not self.sync_free:

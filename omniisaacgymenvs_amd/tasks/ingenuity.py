@@ -92,8 +92,13 @@ class IngenuityTask(RLTask):
             "ball_pos": torch.zeros((n, 3), **f), "ball_rot": torch.zeros((n, 4), **f),
         }
 
-    # ------------------------------------------------------------------ C-ABI argument blocks
+    # ------------------------------------------------------------------ C-ABI argument blocks (cached: RLTask._block keys them
+    # on the identity of the tensors they point into and on the value of their scalars)
     def _params(self) -> _lib.IngenuityParams:
+        sc = (self.dt, self.thrust_limit, self.thrust_lateral_component, self.clip_actions, self._max_episode_length)
+        return self._block("params", (), sc, self._build_params)
+
+    def _build_params(self) -> _lib.IngenuityParams:
         p = _lib.IngenuityParams()
         p.dt, p.thrust_limit, p.thrust_lateral_component = self.dt, self.thrust_limit, self.thrust_lateral_component
         p.clip_actions = float(min(self.clip_actions, 3.0e38))
@@ -101,6 +106,11 @@ class IngenuityTask(RLTask):
         return p
 
     def _buffers(self) -> _lib.IngenuityBuffers:
+        ts = (self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf, self.target_positions, self.thrusts, self.dof_pos,
+              self.dof_vel, self._reset_workspace, self._target_workspace, self._reset_counts_u8, self._target_counts_u8)
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.IngenuityBuffers:
         n, rq = self._num_envs, _lib.require_device_tensor
         rq(self.obs_buf, torch.float32, (n, 13), "obs_buf")
         rq(self.rew_buf, torch.float32, (n,), "rew_buf")
@@ -120,9 +130,12 @@ class IngenuityTask(RLTask):
         return b
 
     def _state(self) -> _lib.IngenuityState:
-        n, rq = self._num_envs, _lib.require_device_tensor
         self.root_pos, self.root_rot = self._copters.get_world_poses(clone=False)
         self.root_velocities = self._copters.get_velocities(clone=False)
+        return self._block("state", (self.root_pos, self.root_rot, self.root_velocities, self._env_pos), (), self._build_state)
+
+    def _build_state(self) -> _lib.IngenuityState:
+        n, rq = self._num_envs, _lib.require_device_tensor
         rq(self.root_pos, torch.float32, (n, 3), "root_pos")
         rq(self.root_rot, torch.float32, (n, 4), "root_rot")
         rq(self.root_velocities, torch.float32, (n, 6), "root_velocities")
@@ -159,6 +172,13 @@ class IngenuityTask(RLTask):
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def _reset_io(self, u_reset=None, u_target=None) -> _lib.IngenuityResetIO:
+        ts = (self.initial_root_pos, self.initial_root_rot, self.initial_ball_rot, self._env_pos, u_reset, u_target,
+              *self._reset_out.values(), self._step_dev if self._capturing else None)
+        r = self._block("reset_io", ts, (self._rand_seed,), lambda: self._build_reset_io(u_reset, u_target))
+        r.step = self._step_count  # the one field that changes from step to step
+        return r
+
+    def _build_reset_io(self, u_reset, u_target) -> _lib.IngenuityResetIO:
         r = _lib.IngenuityResetIO()
         r.initial_root_pos, r.initial_root_rot = self.initial_root_pos.data_ptr(), self.initial_root_rot.data_ptr()
         r.initial_ball_rot, r.env_pos = self.initial_ball_rot.data_ptr(), self._env_pos.data_ptr()
@@ -167,7 +187,6 @@ class IngenuityTask(RLTask):
         if u_target is not None:
             r.u_target = u_target.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
-        r.step = self._step_count
         r.step_ptr = self._graph_step_ptr()
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
@@ -195,12 +214,16 @@ class IngenuityTask(RLTask):
         else:
             self._balls.set_world_poses(o["ball_pos"][:n], o["ball_rot"][:n], indices=o["target_ids"][:n])
 
+    def _checked_actions(self, actions):
+        actions = actions.to(self._device)
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, 6), "actions")
+        return actions
+
     def pre_physics_step(self, actions) -> None:
         if not self.world.is_playing():
             return
         n = self._num_envs
-        actions = actions.to(self._device)
-        _lib.require_device_tensor(actions, torch.float32, (n, 6), "actions")
+        actions = self._block("actions_in", (actions,), (), lambda: self._checked_actions(actions))
         self._advance_step_counter()
         flags, ids = 0, None
         if not self.sync_free:

@@ -181,8 +181,19 @@ class _NewhandCabinetTask(RLTask):
         self.reset_idx(torch.arange(n, dtype=torch.int64, device=dev))
         self.terminate_buf = torch.zeros_like(self.reset_buf)
 
-    # ------------------------------------------------------------------ C-ABI argument blocks
+    # ------------------------------------------------------------------ C-ABI argument blocks (cached: RLTask._block keys them
+    # on the identity of the tensors they point into and on the value of their scalars)
+    _PARAM_SCALARS = ("action_scale", "dof_vel_scale", "dt", "clip_actions", "dist_reward_scale", "rot_reward_scale",
+                      "around_handle_reward_scale", "open_reward_scale", "action_penalty_scale", "AROUND_UPPER", "NUM_DOFS",
+                      "num_actions", "ROT_REWARD_THRESHOLDS", "TERMINATE_ON_LIMITS", "_max_episode_length", "num_props")
+
     def _params(self) -> _lib.NewhandCabinetParams:
+        d = self.__dict__
+        sc = [d[k] if k in d else getattr(self, k) for k in self._PARAM_SCALARS]
+        act = None if self.ACTUATED is None else self.actuated_dof_indices
+        return self._block("params", (self._rows_host, act), sc, self._build_params)
+
+    def _build_params(self) -> _lib.NewhandCabinetParams:
         p, h, D = _lib.NewhandCabinetParams(), self._rows_host, self.NUM_DOFS
         p.action_scale, p.dof_vel_scale, p.dt = self.action_scale, self.dof_vel_scale, self.dt
         p.clip_actions = float(min(self.clip_actions, 3.0e38))
@@ -209,6 +220,12 @@ class _NewhandCabinetTask(RLTask):
         return p
 
     def _buffers(self) -> _lib.NewhandCabinetBuffers:
+        ts = (self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf, self.actions, self.robot_dof_targets,
+              self.keypoints_finger, self.keypoints_drawer, self.terminate_buf, self._reset_workspace, self._tile_counts_u8,
+              getattr(self, "_actuated_targets", None))
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.NewhandCabinetBuffers:
         n, D, rq = self._num_envs, self.NUM_DOFS, _lib.require_device_tensor
         rq(self.obs_buf, torch.float32, (n, 2 * D + 5), "obs_buf")
         rq(self.rew_buf, torch.float32, (n,), "rew_buf")
@@ -233,7 +250,6 @@ class _NewhandCabinetTask(RLTask):
         return b
 
     def _state(self) -> _lib.NewhandCabinetState:
-        n, D, rq = self._num_envs, self.NUM_DOFS, _lib.require_device_tensor
         _, self.left_hand_rot = self._robots._hands.get_world_poses(clone=False)
         fingers = [getattr(self._robots, v).get_world_poses(clone=False) for v in FINGER_VIEWS]
         self.fingers_rot = [r for _, r in fingers]
@@ -242,6 +258,12 @@ class _NewhandCabinetTask(RLTask):
         dof_vel = self._robots.get_joint_velocities(clone=False)
         self.cabinet_dof_pos = self._cabinets.get_joint_positions(clone=False)
         self.cabinet_dof_vel = self._cabinets.get_joint_velocities(clone=False)
+        ts = (self.left_hand_rot, *(t for pr in fingers for t in pr), self.drawer_pos, self.drawer_rot, self.robot_dof_pos, dof_vel,
+              self.cabinet_dof_pos, self.cabinet_dof_vel)
+        return self._block("state", ts, (), lambda: self._build_state(fingers, dof_vel))
+
+    def _build_state(self, fingers, dof_vel) -> _lib.NewhandCabinetState:
+        n, D, rq = self._num_envs, self.NUM_DOFS, _lib.require_device_tensor
         s = _lib.NewhandCabinetState()
         rq(self.left_hand_rot, torch.float32, (n, 4), "left_hand_rot")
         s.hand_rot = self.left_hand_rot.data_ptr()
@@ -283,13 +305,19 @@ class _NewhandCabinetTask(RLTask):
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def _reset_io(self, u_dof=None) -> _lib.FrankaCabinetResetIO:
+        props = (self.default_prop_pos, self.default_prop_rot) if self.num_props > 0 else ()
+        ts = (u_dof, *props, *self._reset_out.values(), self._step_dev if self._capturing else None)
+        r = self._block("reset_io", ts, (self._rand_seed, self.num_props), lambda: self._build_reset_io(u_dof))
+        r.step = self._step_count  # the one field that changes from step to step
+        return r
+
+    def _build_reset_io(self, u_dof) -> _lib.FrankaCabinetResetIO:
         r, o = _lib.FrankaCabinetResetIO(), self._reset_out
         if u_dof is not None:
             r.u_dof = u_dof.data_ptr()
         if self.num_props > 0:
             r.default_prop_pos, r.default_prop_rot = self.default_prop_pos.data_ptr(), self.default_prop_rot.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
-        r.step = self._step_count
         r.step_ptr = self._graph_step_ptr()
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
@@ -314,12 +342,16 @@ class _NewhandCabinetTask(RLTask):
         self._robots.set_joint_positions(o["dof_pos"][sl], **kw)
         self._robots.set_joint_velocities(o["dof_vel"][sl], **kw)
 
+    def _checked_actions(self, actions):
+        actions = actions.to(self._device)
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, self.num_actions), "actions")
+        return actions
+
     def pre_physics_step(self, actions) -> None:
         if not self.world.is_playing():
             return
         n = self._num_envs
-        actions = actions.to(self._device)
-        _lib.require_device_tensor(actions, torch.float32, (n, self.num_actions), "actions")
+        actions = self._block("actions_in", (actions,), (), lambda: self._checked_actions(actions))
         self._advance_step_counter()
         flags = 0
         if not self.sync_free:

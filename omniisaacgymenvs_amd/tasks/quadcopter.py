@@ -97,8 +97,12 @@ class QuadcopterTask(RLTask):
         self._host_consts = {"lower": self.dof_lower_limits.tolist(), "upper": self.dof_upper_limits.tolist(),
                              "max_thrust": float(self.thrust_upper_limits[0])}
 
-    # ------------------------------------------------------------------ C-ABI argument blocks
+    # ------------------------------------------------------------------ C-ABI argument blocks (cached: RLTask._block keys them
+    # on the identity of the tensors they point into and on the value of their scalars)
     def _params(self) -> _lib.QuadcopterParams:
+        return self._block("params", (self._host_consts,), (self.dt, self.clip_actions, self._max_episode_length), self._build_params)
+
+    def _build_params(self) -> _lib.QuadcopterParams:
         p = _lib.QuadcopterParams()
         p.dof_rate = self.dt * (8 * math.pi)     # self.dt * dof_action_speed_scale (:153-154), a Python double product
         p.thrust_rate = self.dt * 100            # :159-160
@@ -110,6 +114,11 @@ class QuadcopterTask(RLTask):
         return p
 
     def _buffers(self) -> _lib.QuadcopterBuffers:
+        ts = (self.obs_buf, self.rew_buf, self.reset_buf, self.progress_buf, self.target_positions, self.dof_position_targets,
+              self.thrusts, self.forces, self._reset_workspace, self._tile_counts_u8)
+        return self._block("buffers", ts, (), self._build_buffers)
+
+    def _build_buffers(self) -> _lib.QuadcopterBuffers:
         n, rq = self._num_envs, _lib.require_device_tensor
         rq(self.obs_buf, torch.float32, (n, 21), "obs_buf")
         rq(self.rew_buf, torch.float32, (n,), "rew_buf")
@@ -128,10 +137,14 @@ class QuadcopterTask(RLTask):
         return b
 
     def _state(self) -> _lib.QuadcopterState:
-        n, rq = self._num_envs, _lib.require_device_tensor
         self.root_pos, self.root_rot = self._copters.get_world_poses(clone=False)
         self.root_velocities = self._copters.get_velocities(clone=False)
         self.dof_pos = self._copters.get_joint_positions(clone=False)
+        ts = (self.root_pos, self.root_rot, self.root_velocities, self.dof_pos, self._env_pos)
+        return self._block("state", ts, (), self._build_state)
+
+    def _build_state(self) -> _lib.QuadcopterState:
+        n, rq = self._num_envs, _lib.require_device_tensor
         rq(self.root_pos, torch.float32, (n, 3), "root_pos")
         rq(self.root_rot, torch.float32, (n, 4), "root_rot")
         rq(self.root_velocities, torch.float32, (n, 6), "root_velocities")
@@ -168,18 +181,29 @@ class QuadcopterTask(RLTask):
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def _reset_io(self, u_dof=None, u_xyz=None) -> _lib.QuadcopterResetIO:
+        ts = (self.initial_root_pos, self.initial_root_rot, u_dof, u_xyz, *self._reset_out.values(),
+              self._step_dev if self._capturing else None)
+        r = self._block("reset_io", ts, (self._rand_seed,), lambda: self._build_reset_io(u_dof, u_xyz))
+        r.step = self._step_count  # the one field that changes from step to step
+        return r
+
+    def _build_reset_io(self, u_dof, u_xyz) -> _lib.QuadcopterResetIO:
         r = _lib.QuadcopterResetIO()
         r.initial_root_pos, r.initial_root_rot = self.initial_root_pos.data_ptr(), self.initial_root_rot.data_ptr()
         if u_dof is not None:
             r.u_dof, r.u_xyz = u_dof.data_ptr(), u_xyz.data_ptr()
         r.seed = int(self._rand_seed) & 0xFFFFFFFFFFFFFFFF
-        r.step = self._step_count
         r.step_ptr = self._graph_step_ptr()
         o = self._reset_out
         r.env_ids, r.count = o["env_ids"].data_ptr(), o["count"].data_ptr()
         r.dof_pos_out, r.dof_vel_out = o["dof_pos"].data_ptr(), o["dof_vel"].data_ptr()
         r.root_pos_out, r.root_rot_out, r.root_vel_out = o["root_pos"].data_ptr(), o["root_rot"].data_ptr(), o["root_vel"].data_ptr()
         return r
+
+    def _checked_actions(self, actions):
+        actions = actions.to(self._device)
+        _lib.require_device_tensor(actions, torch.float32, (self._num_envs, 12), "actions")
+        return actions
 
     def _apply_reset_writes(self, n=None) -> None:
         o = self._reset_out
@@ -196,8 +220,7 @@ class QuadcopterTask(RLTask):
         if not self.world.is_playing():
             return
         n = self._num_envs
-        actions = actions.to(self._device)
-        _lib.require_device_tensor(actions, torch.float32, (n, 12), "actions")
+        actions = self._block("actions_in", (actions,), (), lambda: self._checked_actions(actions))
         self._advance_step_counter()
         flags = 0
         if not self.sync_free:

@@ -407,7 +407,7 @@ def test_step_without_the_scan_launch_equals_the_step_with_it(n):
             inner = task._buffers
 
             def no_u8(inner=inner):
-                b = inner()
+                b = type(inner()).from_buffer_copy(inner())  # a copy: the mirror keeps (and may re-check) its own block
                 b.tile_counts_u8 = None
                 return b
 

@@ -73,7 +73,7 @@ def _ant(n, with_u8):
         inner = task._buffers
 
         def no_u8():
-            b = inner()
+            b = type(inner()).from_buffer_copy(inner())  # a copy: the mirror keeps (and may re-check) its own block
             b.tile_counts_u8 = None
             return b
 

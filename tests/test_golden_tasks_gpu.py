@@ -36,6 +36,7 @@ def _load(name, task, st, b, spec):
         workloads.load_franka_cabinet_state(task, dict(st, prev_actions=b["actions"], targets=b["franka_dof_targets"], **common))
         task._rows_host["franka_local_grasp_pos"] = list(spec.franka_local_grasp_pos)   # the fixture's stand-in for the USD-derived pose
         task._rows_host["franka_local_grasp_rot"] = list(spec.franka_local_grasp_rot)
+        task.invalidate_blocks()   # an in-place edit of a host table the params block was built from (RLTask._block's one blind spot)
     else:
         workloads.load_newhand_cabinet_state(task, dict(st, prev_actions=b["actions"], targets=b["dof_targets"], terminate=b["terminate_buf"],
                                                         **common))

@@ -28,6 +28,7 @@ def _build(name, n, with_u8):
 
         def no_u8(*a, **k):
             s = inner(*a, **k)
+            s = type(s).from_buffer_copy(s)  # a copy: the mirror keeps (and may re-check) its own block
             cleared = 0
             for f in U8_FIELDS:
                 if hasattr(s, f):
