@@ -331,11 +331,21 @@ class AnymalTerrainTask(RLTask):
         return self._height_min
 
     def _buffers(self) -> _lib.AnymalBuffers:
+        # `actions` and `torques` are NEW tensors every step, as in the reference (actions.clone() :390, torch.clip(...) :403):
+        # as parts of the key they made every step a rebuild (17 us of host time); they are rewritten behind the cache instead
         ts = (self.obs_buf, self.rew_buf, self._reset_bool, self.has_fallen, self.timeout_buf, self.progress_buf, self.commands,
-              self.actions, self.last_actions, self.last_dof_vel, self.torques, self.feet_air_time, self._episode_sums,
+              self.last_actions, self.last_dof_vel, self.feet_air_time, self._episode_sums,
               self.terrain_levels, self.terrain_types, self.env_origins, self._extras_dev, self._reset_workspace,
               self._reduce_workspace, self._tile_counts_u8)
-        return self._block("buffers", ts, (), self._build_buffers)
+        b = self._block("buffers", ts, (), self._build_buffers, volatile=("actions", "torques"))
+        a, t = self.actions, self.torques
+        if a.shape != t.shape or a.dtype != torch.float32 or t.dtype != torch.float32 or a.device != self.obs_buf.device \
+                or t.device != a.device or tuple(a.shape) != (self._num_envs, 12) or not (a.is_contiguous() and t.is_contiguous()):
+            _lib.require_device_tensor(a, torch.float32, (self._num_envs, 12), "actions")
+            _lib.require_device_tensor(t, torch.float32, (self._num_envs, 12), "torques")
+            raise _lib.OigeError("AnymalTerrainTask: actions / torques must be contiguous (N, 12) fp32 tensors on the task's device")
+        b.actions, b.torques = a.data_ptr(), t.data_ptr()
+        return b
 
     def _build_buffers(self) -> _lib.AnymalBuffers:
         n = self._num_envs
@@ -409,9 +419,14 @@ class AnymalTerrainTask(RLTask):
         self._anymals.set_joint_velocities(velocities=o["dof_vel"][sl], **kw)
 
     def _bind_extras(self) -> None:
+        # 0-dim views of the device-side means; the views are made once per buffer (fourteen slices were 10 us of every step),
+        # the dict is a new one every step, as in the reference (:361-367)
+        self.extras["episode"] = dict(self._block("extras_views", (self._extras_dev,), (), self._build_extras_views))
+
+    def _build_extras_views(self) -> dict:
         ep = {"rew_" + k: self._extras_dev[i] for i, k in enumerate(EPISODE_KEYS)}
         ep["terrain_level"] = self._extras_dev[len(EPISODE_KEYS)]
-        self.extras["episode"] = ep
+        return ep
 
     # ------------------------------------------------------------------ RLTask methods
     def reset_idx(self, env_ids, draws=None):

@@ -41,13 +41,13 @@ _CHECK_BLOCKS = os.environ.get("OIGE_CHECK_BLOCKS") == "1"
 _VOLATILE_FIELDS = ("step",)  # written by the caller on every call, behind the cache
 
 
-def _assert_same_block(name, cached, fresh) -> None:
+def _assert_same_block(name, cached, fresh, volatile=()) -> None:
     import ctypes
 
     if isinstance(cached, ctypes.Structure):
         for field in cached._fields_:
             f = field[0]
-            if f in _VOLATILE_FIELDS:
+            if f in _VOLATILE_FIELDS or f in volatile:
                 continue
             a, b = getattr(cached, f), getattr(fresh, f)
             if isinstance(a, ctypes.Array):
@@ -57,6 +57,9 @@ def _assert_same_block(name, cached, fresh) -> None:
                 continue
             if a != b and not (a != a and b != b):
                 raise AssertionError(f"cached argument block '{name}' is stale: field {f} is {a!r}, a fresh build gives {b!r}")
+    elif isinstance(cached, dict):
+        for k in cached:
+            _assert_same_block(f"{name}[{k!r}]", cached[k], fresh[k])
     elif isinstance(cached, (tuple, list)):
         for i, (a, b) in enumerate(zip(cached, fresh)):
             _assert_same_block(f"{name}[{i}]", a, b)
@@ -273,7 +276,8 @@ class RLTask:
     # rebound buffer (``task.obs_buf = ...``) or an edited scalar (``task.heading_weight = 0.3``) therefore takes effect on
     # the next call, as before.  Not seen: a tensor whose STORAGE is swapped in place (``.set_()``, ``.resize_()``,
     # ``.data = ...``) -- call ``task.invalidate_blocks()`` after such a change.
-    def _block(self, name, tensors, scalars, build):
+    def _block(self, name, tensors, scalars, build, volatile=()):
+        """``volatile``: fields the caller rewrites on every call behind the cache (not compared in check mode)."""
         key = (*map(id, tensors), *scalars)
         blocks = self.__dict__.get("_blocks")
         if blocks is None:
@@ -281,7 +285,7 @@ class RLTask:
         hit = blocks.get(name)
         if hit is not None and hit[0] == key:
             if _CHECK_BLOCKS:
-                _assert_same_block(name, hit[2], build())
+                _assert_same_block(name, hit[2], build(), volatile)
             return hit[2]
         blk = build()
         blocks[name] = (key, tensors, blk)

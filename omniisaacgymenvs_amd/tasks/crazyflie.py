@@ -238,7 +238,9 @@ class CrazyflieTask(RLTask):
             self._balls.set_world_poses(o["ball_pos"][:n], o["ball_rot"][:n], indices=o["target_ids"][:n])
 
     def _bind_extras(self) -> None:
-        self.extras["episode"] = {k: self._extras_buf[i] for i, k in enumerate(EPISODE_KEYS)}
+        # 0-dim views of the device-side means: made once per buffer, handed out in a new dict every step
+        self.extras["episode"] = dict(self._block("extras_views", (self._extras_buf,), (),
+                                                  lambda: {k: self._extras_buf[i] for i, k in enumerate(EPISODE_KEYS)}))
 
     def _checked_actions(self, actions):
         actions = actions.to(self._device)
