@@ -57,14 +57,12 @@ __device__ __forceinline__ float limit_cost_humanoid(const float (&o)[D], const 
 }
 
 // reward + done for one env from its obs row pieces (locomotion.py:314-345, :290-291)
+// The per-DOF sums of the reward (locomotion.py:322-333; get_dof_at_limit_cost): actions_cost, electricity_cost, the limit cost
 template <int D, int LIMIT>
-__device__ __forceinline__ float reward_of(const oige_locomotion_params& p, float obs0, float up_proj,
-                                           float heading_proj, const float (&dps)[D], const float (&dvs)[D],
-                                           const float (&act)[D], float pot, float prev_pot) {
-  const float hw = p.heading_weight;
-  const float heading_reward = heading_proj > 0.8f ? hw : (hw * heading_proj) / 0.8f;
-  const float up_reward = up_proj > 0.93f ? (0.0f + p.up_weight) : 0.0f;
-  float actions_cost = 0.0f, electricity_cost = 0.0f;
+__device__ __forceinline__ void dof_costs(const oige_locomotion_params& p, const float (&dps)[D], const float (&dvs)[D],
+                                          const float (&act)[D], float& actions_cost, float& electricity_cost, float& lim) {
+  actions_cost = 0.0f;
+  electricity_cost = 0.0f;
 #pragma unroll
   for (int j = 0; j < D; ++j) {
     const float a2 = act[j] * act[j];
@@ -72,7 +70,15 @@ __device__ __forceinline__ float reward_of(const oige_locomotion_params& p, floa
     actions_cost = j == 0 ? a2 : actions_cost + a2;
     electricity_cost = j == 0 ? el : electricity_cost + el;
   }
-  const float lim = LIMIT == 0 ? limit_cost_ant<D>(dps) : limit_cost_humanoid<D>(dps, p);
+  lim = LIMIT == 0 ? limit_cost_ant<D>(dps) : limit_cost_humanoid<D>(dps, p);
+}
+
+// ... and the rest of it, from the head quantities and those three sums
+__device__ __forceinline__ float reward_total(const oige_locomotion_params& p, float obs0, float up_proj, float heading_proj, float pot,
+                                              float prev_pot, float actions_cost, float electricity_cost, float lim) {
+  const float hw = p.heading_weight;
+  const float heading_reward = heading_proj > 0.8f ? hw : (hw * heading_proj) / 0.8f;
+  const float up_reward = up_proj > 0.93f ? (0.0f + p.up_weight) : 0.0f;
   const float progress_reward = pot - prev_pot;
   float total = progress_reward + p.alive_reward_scale;
   total = total + up_reward;
@@ -81,6 +87,15 @@ __device__ __forceinline__ float reward_of(const oige_locomotion_params& p, floa
   total = total - p.energy_cost_scale * electricity_cost;
   total = total - lim;
   return obs0 < p.termination_height ? p.death_cost : total;
+}
+
+template <int D, int LIMIT>
+__device__ __forceinline__ float reward_of(const oige_locomotion_params& p, float obs0, float up_proj,
+                                           float heading_proj, const float (&dps)[D], const float (&dvs)[D],
+                                           const float (&act)[D], float pot, float prev_pot) {
+  float actions_cost, electricity_cost, lim;
+  dof_costs<D, LIMIT>(p, dps, dvs, act, actions_cost, electricity_cost, lim);
+  return reward_total(p, obs0, up_proj, heading_proj, pot, prev_pot, actions_cost, electricity_cost, lim);
 }
 
 // Threads per 64-env tile in the post kernel.  One wave per tile while ten tiles fit a CU's LDS (Ant: 15.4 KB); two waves
@@ -96,7 +111,7 @@ constexpr int post_threads() {
 }
 
 template <int D, int S, int LIMIT, bool FULL>
-__device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__ tile, int64_t t, int nv) {
+__device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__ tile, float* __restrict__ s_sums, int64_t t, int nv) {
   constexpr int OBS = 12 + 3 * D + 6 * S;
   constexpr int PNT = post_threads<D, S>();
   constexpr int C_DPOS = 12, C_DVEL = 12 + D, C_SENS = 12 + 2 * D, C_ACT = 12 + 2 * D + 6 * S;
@@ -150,23 +165,50 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
   scatter_chunk<6 * S, OBS, C_SENS, true, PNT>(c_sens, tile, p.contact_force_scale);
   scatter_chunk<D, OBS, C_ACT, false, PNT>(c_act, tile, 1.0f);
 
-  // ---- C: per-env math (locomotion.py:249-263), one env per lane of the tile's first wave
-  if (PNT != WAVE) __syncthreads();  // B's cross-wave LDS writes visible
+  // ---- C: per-env math (locomotion.py:249-263), one env per lane.  One-wave tiles (Ant): the wave does all of it.  Two-wave
+  // tiles (Humanoid): the first wave takes the head -- quaternion products, Euler angles, potentials -- while the second,
+  // which used to idle through this phase, takes the 3 x D pass over the env's DOF columns (unscale, the two cost sums, the
+  // limit cost) and hands the three sums over through LDS; the phase then lasts as long as the longer half, not their sum
+  // (r03: the tile's LDS footprint holds a CU to seven tiles, so the kernel's rate is tiles x bytes / tile lifetime).  The
+  // operations and their order are those of reward_of: bit-identical.
+  constexpr bool SPLIT = PNT != WAVE;
+  if (SPLIT) __syncthreads();  // B's cross-wave LDS writes visible
+  if (SPLIT && !env_wave) {
+    float* row = tile + lane * OBS;
+    float dps[D], dvs[D], act[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      dps[j] = unscale(row[C_DPOS + j], p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :263
+      dvs[j] = row[C_DVEL + j];
+      act[j] = row[C_ACT + j];
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) row[C_DPOS + j] = dps[j];
+    if (do_metrics) {
+      float ac, ec, lim;
+      dof_costs<D, LIMIT>(p, dps, dvs, act, ac, ec, lim);
+      s_sums[lane] = ac;
+      s_sums[TILE + lane] = ec;
+      s_sums[2 * TILE + lane] = lim;
+    }
+  }
+  float rew = 0.0f, up_proj = 0.f, heading_proj = 0.f, pot = 0.f, prev_pot = 0.f, obs0 = 0.f;
+  float dps[SPLIT ? 1 : D], dvs[SPLIT ? 1 : D], act[SPLIT ? 1 : D];
   if (env_wave) {
   if (do_progress) progress += 1;  // rl_task.py:289, before is_done reads it
 
   const f3 target{p.target[0], p.target[1], p.target[2]};
   f3 to_target{target.x - pos.x, target.y - pos.y, 0.0f};  // :249-250
-  const float prev_pot = pot_in;                           // :252
-  const float pot = (-norm3(to_target)) / p.dt;            // :253
+  prev_pot = pot_in;                                       // :252
+  pot = (-norm3(to_target)) / p.dt;                        // :253
 
   const q4 inv_start{p.inv_start_rot[0], p.inv_start_rot[1], p.inv_start_rot[2], p.inv_start_rot[3]};
   const f3 target_dir = normalize3(to_target);
   const q4 tq = quat_mul(rot, inv_start);
   const f3 up_vec = quat_rotate(tq, f3{p.basis_vec1[0], p.basis_vec1[1], p.basis_vec1[2]});
   const f3 heading_vec = quat_rotate(tq, f3{p.basis_vec0[0], p.basis_vec0[1], p.basis_vec0[2]});
-  const float up_proj = up_vec.z;
-  const float heading_proj = dot3(heading_vec, target_dir);
+  up_proj = up_vec.z;
+  heading_proj = dot3(heading_vec, target_dir);
   const f3 vel_loc = quat_rotate_inverse(tq, lin);
   const f3 angvel_loc = quat_rotate_inverse(tq, ang);
   float roll, pitch, yaw;
@@ -186,11 +228,11 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
   head[9] = normalize_angle(angle_to_target);
   head[10] = up_proj;
   head[11] = heading_proj;
+  obs0 = head[0];
 
-  if (PNT == WAVE) __syncthreads();  // B's cross-lane LDS writes visible (single-wave workgroup: a wave-local fence)
+  if (!SPLIT) __syncthreads();  // B's cross-lane LDS writes visible (single-wave workgroup: a wave-local fence)
 
   float* row = tile + lane * OBS;
-  float dps[D], dvs[D], act[D];
   if (OBS % 4 == 0) {
 #pragma unroll
     for (int k = 0; k < 3; ++k)
@@ -199,14 +241,16 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
 #pragma unroll
     for (int k = 0; k < 12; ++k) row[k] = head[k];
   }
+  if (!SPLIT) {
 #pragma unroll
-  for (int j = 0; j < D; ++j) {
-    dps[j] = unscale(row[C_DPOS + j], p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :263
-    dvs[j] = row[C_DVEL + j];
-    act[j] = row[C_ACT + j];
+    for (int j = 0; j < D; ++j) {
+      dps[j] = unscale(row[C_DPOS + j], p.dof_limits_lower[j], p.dof_limits_upper[j]);  // :263
+      dvs[j] = row[C_DVEL + j];
+      act[j] = row[C_ACT + j];
+    }
+#pragma unroll
+    for (int j = 0; j < D; ++j) row[C_DPOS + j] = dps[j];
   }
-#pragma unroll
-  for (int j = 0; j < D; ++j) row[C_DPOS + j] = dps[j];
 
   if (live) {
     a.b.potentials[env] = pot;
@@ -221,14 +265,23 @@ __device__ __forceinline__ void post_tile(const LocoPost& a, float* __restrict__
     }
     if (do_progress) a.b.progress_buf[env] = progress;
   }
-  float rew = 0.0f;
+  }  // env_wave: head
+  if (SPLIT && do_metrics) __syncthreads();  // the second wave's three sums (do_metrics is uniform)
+  if (env_wave) {
   if (do_metrics) {
-    rew = reward_of<D, LIMIT>(p, head[0], up_proj, heading_proj, dps, dvs, act, pot, prev_pot);
+    if (SPLIT) {
+      rew = reward_total(p, obs0, up_proj, heading_proj, pot, prev_pot, s_sums[lane], s_sums[TILE + lane], s_sums[2 * TILE + lane]);
+    } else {
+      float ac, ec, lim;
+      dof_costs<D, LIMIT>(p, reinterpret_cast<const float (&)[D]>(dps), reinterpret_cast<const float (&)[D]>(dvs),
+                          reinterpret_cast<const float (&)[D]>(act), ac, ec, lim);
+      rew = reward_total(p, obs0, up_proj, heading_proj, pot, prev_pot, ac, ec, lim);
+    }
     if (live) a.b.rew_buf[env] = rew;
   }
   if (do_done) {
     // is_done (:290-291): sticky; progress compared in fp32 against float(max_len - 1)
-    int64_t r = head[0] < p.termination_height ? 1 : reset_in;
+    int64_t r = obs0 < p.termination_height ? 1 : reset_in;
     r = (float)progress >= a.max_len_minus_1 ? 1 : r;
     if (live) a.b.reset_buf[env] = r;
     const unsigned long long m = __ballot(live && r != 0);
@@ -261,12 +314,13 @@ template <int D, int S, int LIMIT>
 __global__ __launch_bounds__((post_threads<D, S>())) void locomotion_post_kernel(const LocoPost a) {
   constexpr int OBS = 12 + 3 * D + 6 * S;
   __shared__ __align__(16) float tile[TILE * OBS];
+  __shared__ float s_sums[post_threads<D, S>() != WAVE ? 3 * TILE : 1];  // two-wave tiles: the second wave's three sums per env
   const int64_t t = blockIdx.x;
   const int64_t left = a.n - t * TILE;
   if (left >= TILE)
-    post_tile<D, S, LIMIT, true>(a, tile, t, TILE);
+    post_tile<D, S, LIMIT, true>(a, tile, s_sums, t, TILE);
   else
-    post_tile<D, S, LIMIT, false>(a, tile, t, (int)left);
+    post_tile<D, S, LIMIT, false>(a, tile, s_sums, t, (int)left);
 }
 
 // ---------------------------------------------------------------- split-stage kernels
