@@ -117,11 +117,15 @@ def test_post_physics_matches_oracle(cfg_name, n, fused):
 
 
 @pytest.mark.parametrize("cfg_name", ["full", "full/mcs+ema"])
-@pytest.mark.parametrize("n,relative", [(64, False), (1000, False), (1000, True)])
-def test_sync_free_pre_physics_matches_oracle(cfg_name, n, relative):
+@pytest.mark.parametrize("n,relative,p_reset,p_goal", [
+    (64, False, 0.2, 0.3), (1000, False, 0.2, 0.3), (1000, True, 0.2, 0.3),
+    (1000, False, 0.8, 0.3),   # more reset envs per 256-env group than the kernel stages in LDS
+    (1000, True, 0.05, 0.9),   # > 128 goal-only envs per group: lanes hold a goal role and a reset role at once
+    (700, False, 1.0, 1.0)])
+def test_sync_free_pre_physics_matches_oracle(cfg_name, n, relative, p_reset, p_goal):
     env, task, st = _loaded(cfg_name, n, useRelativeControl=relative)
-    st["reset"] = (torch.rand(n, generator=torch.Generator().manual_seed(3)) < 0.2).long()
-    st["reset_goal"] = (torch.rand(n, generator=torch.Generator().manual_seed(4)) < 0.3).long()
+    st["reset"] = (torch.rand(n, generator=torch.Generator().manual_seed(3)) < p_reset).long()
+    st["reset_goal"] = (torch.rand(n, generator=torch.Generator().manual_seed(4)) < p_goal).long()
     workloads.load_hand_state(task, st)
     spec, b = _spec(task), _oracle_buffers(task)
     init = ho.HandInit(task.object_init_pos.cpu(), task.goal_init_pos.cpu(), task._env_pos.cpu(),

@@ -141,13 +141,16 @@ def test_no_resets_leaves_consecutive_successes_unchanged():
 
 
 @pytest.mark.parametrize("cfg_name", ["ShadowHand", "ShadowHandOpenAI_FF"])
-@pytest.mark.parametrize("n,relative,p_reset", [(64, False, 0.2), (1000, False, 0.2), (1000, True, 0.2),
-                                                (1000, False, 0.7),   # > 64 reset envs per 256-env group: the rows past the
-                                                (600, True, 1.0)])    # kernel's LDS staging (HAND_RMAX) take the per-lane path
-def test_sync_free_pre_physics_matches_oracle(cfg_name, n, relative, p_reset):
+@pytest.mark.parametrize("n,relative,p_reset,p_goal", [
+    (64, False, 0.2, 0.3), (1000, False, 0.2, 0.3), (1000, True, 0.2, 0.3),
+    (1000, False, 0.7, 0.3),   # > 64 reset envs per 256-env group: the rows past the kernel's LDS staging (HAND_RMAX) take the
+    (600, True, 1.0, 0.3),     # per-lane path
+    (1000, False, 0.05, 0.9),  # > 128 goal-only envs per group: lanes hold a goal role and a reset role at once
+    (700, True, 0.5, 1.0)])    # every lane of a group has a role, most of them two
+def test_sync_free_pre_physics_matches_oracle(cfg_name, n, relative, p_reset, p_goal):
     env, task, st = _loaded(cfg_name, n, useRelativeControl=relative)
     st["reset"] = (torch.rand(n, generator=torch.Generator().manual_seed(3)) < p_reset).long()
-    st["reset_goal"] = (torch.rand(n, generator=torch.Generator().manual_seed(4)) < 0.3).long()
+    st["reset_goal"] = (torch.rand(n, generator=torch.Generator().manual_seed(4)) < p_goal).long()
     workloads.load_hand_state(task, st)
     spec, b = _spec(task), _oracle_buffers(task)
     init = ho.HandInit(task.object_init_pos.cpu(), task.goal_init_pos.cpu(), task._env_pos.cpu(),
