@@ -27,7 +27,6 @@ constexpr int AD = OIGE_ANYMAL_DOFS;          // 12
 constexpr int AO = OIGE_ANYMAL_OBS;           // 188
 constexpr int AP = OIGE_ANYMAL_SCAN_POINTS;   // 140
 constexpr int AE = OIGE_ANYMAL_EPISODE_SUMS;  // 13
-constexpr int ANT = 256;
 constexpr int RW = 16;  // reduce_workspace floats per tile
 
 struct AnymalPost {
@@ -773,23 +772,12 @@ static void launch_anymal_head(const AnymalPost& a, int64_t T, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------ height scan (:582-604, :537-539)
-// One 256-thread workgroup per tile, from the pose records the head kernel left.  Each wave takes chunks of 256
-// consecutive points (64 float4 of scan columns): NG passes with ONE POINT PER LANE (64 neighbouring points of one env
-// per gather instruction, all gathers of a chunk issued before the first is consumed) into a per-wave LDS strip; then
-// one float4 per lane out of the strip, plus its noise, straight to obs_buf.  Light on registers and LDS on purpose:
-// the gathers are L2 / Infinity-Cache latency, hidden by resident waves.
-// The scan is VALU-issue bound (not gather bound: dropping both gathers saves 20 %), so the loop is kept lean:
-//  * quat_apply(q_yaw, (hx, hy, 0)) with q_yaw = (w, 0, 0, z) (:608-612), with the terms that are exactly zero removed
-//    (the surviving products, sums and their order are oige_math.hpp's quat_apply: t = 2 (qv x v); v + w t + qv x t, so
-//    every finite result is bit-identical):  t = (tx, ty, 0) = (-(2 z hy), 2 z hx, 0),
-//    rx = (hx + w tx) + (-(z ty)),  ry = (hy + w ty) + (z tx).  tx depends on the grid column only and ty on the grid
-//    row only: their four products are tabulated once per env (24 entries instead of 140 x 6 multiplies);
-//  * (env, point) cursors advance incrementally, no integer division in the loop;
-//  * x / horizontal_scale through div_by_const.
-constexpr int ANG = 4;
-// per-env scan table (floats): AB[iy] = (w tx, z tx) for the 10 grid columns, CD[ix] = (z ty, w ty) for the 14 grid
-// rows, then (base x, base y, base z - 0.5, -).  13 float4 per env (odd): conflict-free 16-byte rows.
-constexpr int AER = 52, AE_CD = 20, AE_POS = 48;
+// From the pose records the head kernel left.  quat_apply(q_yaw, (hx, hy, 0)) with q_yaw = (w, 0, 0, z) (:608-612), with the
+// terms that are exactly zero removed (the surviving products, sums and their order are oige_math.hpp's quat_apply:
+// t = 2 (qv x v); v + w t + qv x t, so every finite result is bit-identical):  t = (tx, ty, 0) = (-(2 z hy), 2 z hx, 0),
+// rx = (hx + w tx) + (-(z ty)),  ry = (hy + w ty) + (z tx).  tx depends on the grid column only and ty on the grid row only:
+// their four products are formed once per env (24 values instead of 140 x 6 multiplies); x / horizontal_scale through
+// div_by_const.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // div_by_const on both halves of a float2 (the same five IEEE operations per half)
@@ -813,182 +801,179 @@ __device__ __forceinline__ void cursor_advance(int& e, int& k, int de, int dk, i
   if (k >= period) { k -= period; e += 1; }
 }
 
-// HMIN: the tabulated min is there (a compile-time split: as a run-time test inside the loop every gather sat in its own
-// conditional block followed by a full wait, one exposed round trip per pass)
-template <bool FULLTILE, bool HMIN, bool NOISE_IN>
-__device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __restrict__ s_env, float* __restrict__ s_k,
-                                                 float* __restrict__ s_strip, int64_t t, int nv) {
+
+// ONE LANE PER (env, grid column iy), the 14 grid rows ix unrolled in the lane; 32 envs = 320 threads per workgroup.
+// Everything that depends on (env, iy) -- hy, w tx, z tx, the base position -- is a lane constant in registers, everything that
+// depends on ix is a compile-time constant (hx) or one of two 8-byte LDS reads per PAIR of rows (-(z ty), w ty: 28 floats per
+// env, tabulated by the env's own ten lanes) at immediate offsets from one per-lane base.  The packed operations pair two grid
+// ROWS of one coordinate instead of the two coordinates of one point, so no operand has to be assembled from two sources.
+// The 14 heights of a lane are gathered together; the observations are collected in LDS in the order of obs_buf's scan
+// columns (float4 i of the tile is float4 i of its part of the buffer) and leave as float4 with their noise.  The noise of a
+// float4 depends on its position alone, so its draws (twenty dependent 32 x 32 -> 64-bit multiplies each, the longest chain
+// of the kernel) fill the two waits of a workgroup's life: half of them behind the load of the pose records, half behind
+// the gathers.
+// The r01-r03 kernel (git: 49f661b and before) walked 256-point chunks with one point per lane: per point it read four table
+// entries through computed LDS addresses, advanced two (env, k) cursors and shuffled the halves of its operand pairs -- a
+// quarter of the 250 instructions of its loop -- and drew its noise behind the gathers' wait.  Same values, bit for bit:
+// 70.0 -> 66.4 us.  What else was tried (one lane per point for the gathers, resident workgroups fed by a queue or a fixed
+// stride, staggered starts) and what the ablations say: profiles/r03/anymal_scan_layout.txt, DESIGN.md 3.0.
+constexpr int STILE = 32;        // envs per scan workgroup
+constexpr int SNT = STILE * 10;  // 320 threads (5 waves): thread j = env j / 10, grid column j % 10
+constexpr int SCD = 28;          // per-env LDS table: -(z ty)[14], (w ty)[14]
+__host__ __device__ inline int64_t scan_tiles(int64_t n) { return (n + STILE - 1) / STILE; }
+__host__ __device__ constexpr float scan_hx(int ix) { return 0.1f * (float)(ix < 7 ? ix - 8 : ix - 5); }  // :178-180
+
+template <bool HMIN, bool NOISE_IN>
+__device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __restrict__ s_cd, float* __restrict__ s_out,
+                                                 int64_t t, int nv) {
   const oige_anymal_params& p = a.p;
   const int tid = threadIdx.x;
   const uint64_t noise_step = step_of(a.r);
-  const int64_t env0 = t * TILE;
+  const int64_t env0 = t * STILE;
   const float* pose_in = a.b.reduce_workspace + pose_offset(num_tiles(a.n)) + env0 * APOSE;
-  if (tid < AP) {  // meshgrid(x, y, indexing='ij') flattened: k = ix * 10 + iy
-    const int ix = tid / 10, iy = tid % 10;
-    const float hx = 0.1f * (float)(ix < 7 ? ix - 8 : ix - 5);  // :178-180
-    const float hy = 0.1f * (float)(iy < 5 ? iy - 5 : iy - 4);  // :175-177
-    *reinterpret_cast<float4*>(s_k + 4 * tid) = make_float4(hx, hy, __int_as_float(8 * iy), __int_as_float(4 * AE_CD + 8 * ix));
-  }
-  {
-    constexpr int ENTRIES = TILE * 25;  // 24 table entries + the position record per env
-    constexpr int EIT = (ENTRIES + ANT - 1) / ANT;
-    // every pose record this thread needs, fetched in one go through clamped indices (r03: inside the loop below each was a
-    // conditional load with a full wait behind it -- seven serial round trips to the records the head kernel has just written,
-    // on another XCD as often as not, in front of every workgroup's scan)
-    float4 qs[EIT];
-    float zs[EIT];
-#pragma unroll
-    for (int it = 0; it < EIT; ++it) {
-      const int i = it * ANT + tid;
-      int e = (i < ENTRIES ? i : ENTRIES - 1) / 25;
-      if (!FULLTILE) e = e < nv ? e : nv - 1;
-      qs[it] = *reinterpret_cast<const float4*>(pose_in + e * APOSE);  // w, z, x, y
-      zs[it] = pose_in[e * APOSE + 4];
+  const int e = tid / 10, iy = tid - 10 * e;
+  const int e_ld = e < nv ? e : nv - 1;  // lanes past a ragged tile's end repeat its last env; nothing of theirs is stored
+#ifdef OIGE_EXP_SCAN_YAW
+  float4 q = *reinterpret_cast<const float4*>(pose_in + e_ld * APOSE);
+  q.x = OIGE_EXP_SCAN_YAW == 0 ? 1.0f : 0.70710678f;
+  q.y = OIGE_EXP_SCAN_YAW == 0 ? 0.0f : 0.70710678f;
+#else
+  const float4 q = *reinterpret_cast<const float4*>(pose_in + e_ld * APOSE);  // yaw quat w, z, base x, base y
+#endif
+  const float pz = pose_in[e_ld * APOSE + 4];                                  // base z - 0.5
+
+  // the float4 this thread sends out at the end: i = tid + 320 ps of the tile = float4 fk = i % 35 of env i / 35
+  constexpr int F4 = STILE * AP4;  // 1120
+  constexpr int NPASS = (F4 + SNT - 1) / SNT;
+#ifdef OIGE_EXP_SCAN_EARLY
+  constexpr int EARLY = OIGE_EXP_SCAN_EARLY;
+#else
+  constexpr int EARLY = NPASS / 2;  // draws behind the pose load; the others behind the gathers
+#endif
+  static_assert(AO % 4 == 0 && AP % 4 == 0, "whole float4 per observation row");
+  float4 nz[NPASS];
+  uint32_t gfs[NPASS];
+  const float nscale = p.noise_scales[5];
+  int fe = tid / AP4, fk = tid - AP4 * fe;
+  auto draw = [&](int ps) {
+    gfs[ps] = __umul24((uint32_t)env0 + (uint32_t)fe, (uint32_t)(AO / 4)) + 9u + (uint32_t)fk;  // env < 2^23
+    const bool live = fe < nv && (ps * SNT + SNT <= F4 || ps * SNT + tid < F4);
+    if (!live) gfs[ps] = 0xffffffffu;
+    nz[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef OIGE_EXP_NO_NOISE
+    if (p.add_noise && live) {
+      float uu[4];
+      anymal_noise4<NOISE_IN>(a.r, noise_step, gfs[ps], uu);
+      nz[ps] = make_float4((2.0f * uu[0] - 1.0f) * nscale, (2.0f * uu[1] - 1.0f) * nscale, (2.0f * uu[2] - 1.0f) * nscale,
+                           (2.0f * uu[3] - 1.0f) * nscale);
     }
+#endif
+    cursor_advance(fe, fk, SNT / AP4, SNT % AP4, AP4);  // + 320 float4 = 9 envs + 5
+  };
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int it = 0; it < EIT; ++it) {
-      const int i = it * ANT + tid;
-      if (i >= ENTRIES) continue;
-      const int e = i / 25, j = i - 25 * e;
-      if (!FULLTILE && e >= nv) continue;
-      const float4 q = qs[it];
-      if (j < 10) {
-        const float hy = 0.1f * (float)(j < 5 ? j - 5 : j - 4);
-        const float tx = -((q.y * hy) * 2.0f);
-        *reinterpret_cast<float2*>(s_env + e * AER + 2 * j) = make_float2(q.x * tx, q.y * tx);
-      } else if (j < 24) {
-        const int ix = j - 10;
-        const float hx = 0.1f * (float)(ix < 7 ? ix - 8 : ix - 5);
-        const float ty = (q.y * hx) * 2.0f;
-        *reinterpret_cast<float2*>(s_env + e * AER + 2 * j) = make_float2(q.y * ty, q.x * ty);
-      } else {
-        *reinterpret_cast<float4*>(s_env + e * AER + AE_POS) = make_float4(q.z, q.w, zs[it], 0.f);
-      }
+  for (int ps = 0; ps < EARLY; ++ps) draw(ps);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // meshgrid(x, y, indexing='ij') flattened: k = ix * 10 + iy
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // the env's lane iy tabulates rows ix = iy and ix = iy + 10
+    const int ix = iy + 10 * h;
+    const float hx = 0.1f * (float)(ix < 7 ? ix - 8 : ix - 5);
+    const float ty = (q.y * hx) * 2.0f;
+    if (h == 0 || iy < 4) {
+      s_cd[e * SCD + ix] = -(q.y * ty);
+      s_cd[e * SCD + 14 + ix] = q.x * ty;
     }
   }
+  const float hy = 0.1f * (float)(iy < 5 ? iy - 5 : iy - 4);  // :175-177
+  const float tx = -((q.y * hy) * 2.0f);
+  const float wtx = q.x * tx, ztx = q.y * tx;
   __syncthreads();
 #ifndef OIGE_EXP_NO_SCAN
   const int hs_cols = p.hs_cols, max_r = p.hs_rows - 2, max_c = p.hs_cols - 2;
   const float hscale = p.horizontal_scale, hinv = 1.0f / p.horizontal_scale;
-  const float nscale = p.noise_scales[5];
   const v2f border = {p.border_size, p.border_size};
   const char* hmin = reinterpret_cast<const char*>(a.s.height_min);  // NULL (HMIN false) -> the reference's two gathers
-  const int wave = tid >> 6, lane = tid & (WAVE - 1);
-  constexpr int NW = ANT / WAVE;
-  float* strip = s_strip + wave * 256;
-  constexpr int CHUNKS = TILE * AP / 256;  // 35
-  static_assert(TILE * AP % 256 == 0, "whole chunks");
-  // point cursor (env, k) of pass 0 of chunk `wave`; float4 cursor (env, k4) of its output
-  int pe = (wave * 256 + lane) / AP, pk = (wave * 256 + lane) - pe * AP;
-  int fe = (wave * WAVE + lane) / AP4, fk = (wave * WAVE + lane) - fe * AP4;
-#pragma unroll 1
-  for (int c = wave; c < CHUNKS; c += NW) {
-    int idx[ANG];
-    float pz[ANG];
-    // The four passes advance STAGE BY STAGE (every pass's table reads, then every pass's first sum, ...): a packed fp32
-    // operation needs a free issue slot before a dependent one, and written pass by pass each of the nine in a pass's
-    // chain was followed by an idle slot.
-    v2f hxy[ANG], t1[ANG], t2[ANG], bxy[ANG];
+  const float* cd = s_cd + e * SCD;
+  constexpr int NR = 14;
+  uint32_t o1[NR];
+  // rx = (hx + w tx) + (-(z ty)), ry = (hy + w ty) + (z tx); then ((r + base) + border) / horizontal_scale (:586-593) as
+  // div_by_const2's five operations; .long() truncates toward zero, and so does v_cvt_i32_f32, which also saturates: the
+  // clip that follows (:596-597) maps every saturated value where int64 truncation + clip would
 #pragma unroll
-    for (int g = 0; g < ANG; ++g) {
-      const float4 kk = lds4(s_k + 4 * pk);  // hx, hy, AB offset, CD offset
-      const char* eb = reinterpret_cast<const char*>(s_env) + __mul24(pe, AER * 4);  // (v_mul_lo_u32 is quarter rate)
-      const float2 ab = *reinterpret_cast<const float2*>(eb + __float_as_int(kk.z));
-      const float2 cd = *reinterpret_cast<const float2*>(eb + __float_as_int(kk.w));
-      const float4 pp = *reinterpret_cast<const float4*>(eb + 4 * AE_POS);  // base x, y, z - 0.5
-      // both components per instruction (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: the same IEEE operation on each half)
-      hxy[g] = v2f{kk.x, kk.y}; t1[g] = v2f{ab.x, cd.y}; t2[g] = v2f{-cd.x, ab.y}; bxy[g] = v2f{pp.x, pp.y};
-      pz[g] = pp.z;
-      // next pass: +64 points; after the last pass, the first pass of the wave's next chunk: +4*256 - 192 = 5*140 + 132
-      if (g != ANG - 1) cursor_advance(pe, pk, 0, 64, AP);
-      else cursor_advance(pe, pk, 5, 132, AP);
-    }
-    v2f x[ANG], q[ANG], r[ANG];
-    const v2f hh = {hscale, hscale}, ii = {hinv, hinv};
-    // rx = (hx + w tx) + (-(z ty)), ry = (hy + w ty) + (z tx); then ((r + base) + border) / horizontal_scale (:586-593)
-    // as div_by_const2's five operations
+  for (int m = 0; m < NR / 2; ++m) {
+    const v2f nzty = *reinterpret_cast<const v2f*>(cd + 2 * m);
+    const v2f wty = *reinterpret_cast<const v2f*>(cd + 14 + 2 * m);
+    v2f x = v2f{scan_hx(2 * m), scan_hx(2 * m + 1)} + v2f{wtx, wtx};
+    v2f y = v2f{hy, hy} + wty;
+    x = x + nzty;
+    y = y + v2f{ztx, ztx};
+    x = x + v2f{q.z, q.z};
+    y = y + v2f{q.w, q.w};
+    x = x + border;
+    y = y + border;
+    const v2f qx = div_by_const2(x, hscale, hinv), qy = div_by_const2(y, hscale, hinv);
+    // byte offsets into the int16 map (< 2 GiB): both factors below 2^24, v_mad_i32_i24 is full rate; unsigned 32-bit, so the
+    // gathers take the table's base from scalar registers and the offset as it is
+    o1[2 * m] = 2u * (uint32_t)(__mul24(clip_index((int)qx.x, max_r), hs_cols) + clip_index((int)qy.x, max_c));
+    o1[2 * m + 1] = 2u * (uint32_t)(__mul24(clip_index((int)qx.y, max_r), hs_cols) + clip_index((int)qy.y, max_c));
+  }
+  int32_t hv[NR];
+  // every gather of the lane leaves before the first is consumed
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < ANG; ++g) x[g] = hxy[g] + t1[g];
-#pragma unroll
-    for (int g = 0; g < ANG; ++g) x[g] = x[g] + t2[g];
-#pragma unroll
-    for (int g = 0; g < ANG; ++g) x[g] = x[g] + bxy[g];
-#pragma unroll
-    for (int g = 0; g < ANG; ++g) x[g] = x[g] + border;
-#pragma unroll
-    for (int g = 0; g < ANG; ++g) q[g] = x[g] * ii;
-#pragma unroll
-    for (int g = 0; g < ANG; ++g) r[g] = __builtin_elementwise_fma(-q[g], hh, x[g]);
-#pragma unroll
-    for (int g = 0; g < ANG; ++g) q[g] = __builtin_elementwise_fma(r[g], ii, q[g]);
-#pragma unroll
-    for (int g = 0; g < ANG; ++g) r[g] = __builtin_elementwise_fma(-q[g], hh, x[g]);
-#pragma unroll
-    for (int g = 0; g < ANG; ++g) q[g] = __builtin_elementwise_fma(r[g], ii, q[g]);
-#pragma unroll
-    for (int g = 0; g < ANG; ++g) {
-      // .long() truncates toward zero; v_cvt_i32_f32 does too and saturates, and the clip that follows (:596-597) maps
-      // every saturated value where int64 truncation + clip would (out-of-range low -> 0, high -> rows - 2)
-      const int px = clip_index((int)q[g].x, max_r), py = clip_index((int)q[g].y, max_c);
-      idx[g] = __mul24(px, hs_cols) + py;  // both below 2^24: v_mad_i32_i24 is full rate, v_mul_lo_u32 quarter rate
-    }
-    int16_t h1[ANG], h2[ANG];
-    // every gather of the chunk leaves before the first is consumed: without the fences the scheduler interleaves the last
-    // pass's index arithmetic with the first passes' conversions and puts a full wait in front of the last gather (two exposed
-    // round trips per chunk instead of one; r03)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < ANG; ++g) {
+  for (int g = 0; g < NR; ++g) {
 #if defined(OIGE_EXP_SCAN_NOGATHER)
-      h1[g] = (int16_t)idx[g];
-      h2[g] = (int16_t)(idx[g] >> 3);
+    hv[g] = (int16_t)o1[g];
 #else
-      // unsigned 32-bit element offsets: the gathers take the table's base from scalar registers and the offset as it
-      // is (no sign extension, no 64-bit address arithmetic per lane)
-      const uint32_t o1 = 2u * (uint32_t)idx[g], o2 = o1 + 2u * (uint32_t)(hs_cols + 1);  // byte offsets (the map is < 2 GiB)
-      if (HMIN) {  // min(h[px, py], h[px + 1, py + 1]) tabulated per map: one gather (oige_anymal_height_min)
-        h1[g] = h2[g] = *reinterpret_cast<const int16_t*>(hmin + o1);
-      } else {
-        const char* hb = reinterpret_cast<const char*>(a.s.height_samples);
-        h1[g] = *reinterpret_cast<const int16_t*>(hb + o1);
-        h2[g] = *reinterpret_cast<const int16_t*>(hb + o2);
-      }
-#endif
+    if (HMIN) {  // min(h[px, py], h[px + 1, py + 1]) tabulated per map: one gather (oige_anymal_height_min)
+      hv[g] = *reinterpret_cast<const int16_t*>(hmin + o1[g]);
+    } else {
+      const char* hb = reinterpret_cast<const char*>(a.s.height_samples);
+      const int16_t h1 = *reinterpret_cast<const int16_t*>(hb + o1[g]);
+      const int16_t h2 = *reinterpret_cast<const int16_t*>(hb + (o1[g] + 2u * (uint32_t)(hs_cols + 1)));
+      hv[g] = h1 < h2 ? h1 : h2;
     }
-    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int g = 0; g < ANG; ++g) {
-      const float mh = (float)(h1[g] < h2[g] ? h1[g] : h2[g]) * p.vertical_scale;
-      const float hv = pz[g] - mh;
-      const float cl = __builtin_fminf(__builtin_fmaxf(hv, -1.0f), 1.0f);
-      strip[g * WAVE + lane] = ((hv != hv) ? hv : cl) * p.height_meas_scale;  // torch.clip keeps NaN
+  for (int ps = EARLY; ps < NPASS; ++ps) draw(ps);
+  __builtin_amdgcn_sched_barrier(0);
+  // torch.clip keeps NaN where the median instruction returns a bound.  The heights are finite (int16 x vertical_scale),
+  // so the difference is NaN only where base z is: one test per wave instead of two instructions per point
+  const bool odd = (pz != pz) || !(__builtin_fabsf(p.vertical_scale) < __builtin_inff());
+  float* out = s_out + e * AP + iy;
+  if (__builtin_amdgcn_ballot_w64(odd) == 0) {
+#pragma unroll
+    for (int g = 0; g < NR; ++g) {
+      const float hd = pz - (float)hv[g] * p.vertical_scale;
+      out[10 * g] = __builtin_fminf(__builtin_fmaxf(hd, -1.0f), 1.0f) * p.height_meas_scale;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-      float4 v = lds4(strip + 4 * lane);
-      static_assert(AO % 4 == 0, "whole float4 per observation row");
-      const uint32_t gf = __umul24((uint32_t)env0 + (uint32_t)fe, (uint32_t)(AO / 4)) + 9u + (uint32_t)fk;  // env < 2^23
-      const int64_t off = 4 * (int64_t)gf;  // (env0 + fe) * AO + 36 + 4 * fk
-      if (FULLTILE || fe < nv) {
-#ifndef OIGE_EXP_NO_NOISE
-        if (p.add_noise) {
-          float uu[4];
-          anymal_noise4<NOISE_IN>(a.r, noise_step, gf, uu);
-          v.x = v.x + (2.0f * uu[0] - 1.0f) * nscale;
-          v.y = v.y + (2.0f * uu[1] - 1.0f) * nscale;
-          v.z = v.z + (2.0f * uu[2] - 1.0f) * nscale;
-          v.w = v.w + (2.0f * uu[3] - 1.0f) * nscale;
-        }
+  } else {
+#pragma unroll
+    for (int g = 0; g < NR; ++g) {
+      const float hd = pz - (float)hv[g] * p.vertical_scale;
+      const float cl = __builtin_fminf(__builtin_fmaxf(hd, -1.0f), 1.0f);
+      out[10 * g] = ((hd != hd) ? hd : cl) * p.height_meas_scale;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    if (gfs[ps] == 0xffffffffu) continue;
+    float4 v = lds4(s_out + 4 * (ps * SNT + tid));
+    if (p.add_noise) {  // (x + 0 would turn a -0 into +0)
+      v.x = v.x + nz[ps].x;
+      v.y = v.y + nz[ps].y;
+      v.z = v.z + nz[ps].z;
+      v.w = v.w + nz[ps].w;
+    }
+#ifdef OIGE_EXP_SCAN_NOSTORE
+    if (v.x == 123456.75f)
 #endif
-        ANYMAL_SCAN_ST4(a.b.obs_buf + off, v);
-      }
-      cursor_advance(fe, fk, 7, 11, AP4);  // the wave's next chunk: +4 * 64 float4 = 7 * 35 + 11
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    ANYMAL_SCAN_ST4(a.b.obs_buf + 4 * (int64_t)gfs[ps], v);  // (env0 + fe) * AO + 36 + 4 * fk
   }
 #endif
 }
@@ -1028,26 +1013,32 @@ __device__ __forceinline__ void anymal_extras_body(const AnymalPost& a, double (
 }
 
 // Workgroup 0 folds the extras while the others scan (a one-workgroup, latency-bound reduction that would otherwise run
-// alone for ~12 us after the scan): workgroup b > 0 owns tile b - 1.
-__global__ __launch_bounds__(ANT) void anymal_scan_kernel(const AnymalPost a) {
-  __shared__ __align__(16) float s_env[TILE * AER];
-  __shared__ __align__(16) float s_k[AP * 4];
-  __shared__ __align__(16) float s_strip[(ANT / WAVE) * 256];
+// alone for ~12 us after the scan): workgroup b > 0 owns scan tile b - 1 (STILE envs).
+#ifdef OIGE_EXP_SCAN_OCC
+#define SCAN_OCC __attribute__((amdgpu_waves_per_eu(OIGE_EXP_SCAN_OCC, OIGE_EXP_SCAN_OCC)))
+#else
+#define SCAN_OCC
+#endif
+__global__ __launch_bounds__(SNT) SCAN_OCC void anymal_scan_kernel(const AnymalPost a) {
+  __shared__ __align__(16) float s_out[STILE * AP];
+  __shared__ __align__(16) float s_cd[STILE * SCD];
   if (blockIdx.x == 0) {
-    static_assert(sizeof(double) * (ANT / WAVE) * (AE + 1) <= sizeof(float) * TILE * AER, "extras partials fit in s_env");
-    if (a.stages == 0) anymal_extras_body<ANT>(a, reinterpret_cast<double (*)[AE + 1]>(s_env));  // (get_observations alone resets nothing)
+    static_assert(sizeof(double) * (SNT / WAVE) * (AE + 1) <= sizeof(float) * STILE * AP, "extras partials fit in s_out");
+    if (a.stages == 0) anymal_extras_body<SNT>(a, reinterpret_cast<double (*)[AE + 1]>(s_out));  // (get_observations alone resets nothing)
     return;
   }
   const int64_t t = (int64_t)blockIdx.x - 1;
-  const int64_t left = a.n - t * TILE;
-  // the product path (tabulated min, Philox noise, whole tile) is one specialisation; the others share slower generic ones
+  const int64_t left = a.n - t * STILE;
+  const int nv = left >= STILE ? STILE : (int)left;
+  // the product path (tabulated min, Philox noise) is one specialisation; the others share slower generic ones
   const bool hmin = a.s.height_min != nullptr, noise_in = a.r.noise_u != nullptr;
-  const int nv = left >= TILE ? TILE : (int)left;
-  if (left >= TILE && hmin && !noise_in) anymal_scan_tile<true, true, false>(a, s_env, s_k, s_strip, t, TILE);
-  else if (hmin && !noise_in) anymal_scan_tile<false, true, false>(a, s_env, s_k, s_strip, t, nv);
-  else if (hmin) anymal_scan_tile<false, true, true>(a, s_env, s_k, s_strip, t, nv);
-  else if (!noise_in) anymal_scan_tile<false, false, false>(a, s_env, s_k, s_strip, t, nv);
-  else anymal_scan_tile<false, false, true>(a, s_env, s_k, s_strip, t, nv);
+  if (hmin && !noise_in) anymal_scan_tile<true, false>(a, s_cd, s_out, t, nv);
+  else if (hmin) anymal_scan_tile<true, true>(a, s_cd, s_out, t, nv);
+  else if (!noise_in) anymal_scan_tile<false, false>(a, s_cd, s_out, t, nv);
+  else anymal_scan_tile<false, true>(a, s_cd, s_out, t, nv);
+}
+__host__ inline void launch_anymal_scan(const AnymalPost& a, hipStream_t st) {
+  hipLaunchKernelGGL(anymal_scan_kernel, dim3((unsigned)scan_tiles(a.n) + 1), dim3(SNT), 0, st, a);
 }
 
 // update_terrain_level(env_ids) on its own (:369-380; reset_idx runs it inside the head kernel).  One workgroup: the
@@ -1213,7 +1204,7 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
       launch_anymal_head(a, T, st);
       if (int rc = check_launch("anymal_head_kernel")) return rc;
       if (stages & OIGE_ANYMAL_STAGE_OBS) {
-        hipLaunchKernelGGL(anymal_scan_kernel, dim3((unsigned)T + 1), dim3(ANT), 0, st, a);
+        launch_anymal_scan(a, st);
         return check_launch("anymal_scan_kernel");
       }
     }
@@ -1229,7 +1220,7 @@ static int anymal_launch(const oige_anymal_params* params, const oige_anymal_sta
   launch_anymal_head(a, T, st);
   if (int rc = check_launch("anymal_head_kernel")) return rc;
   if (mode == 0) {  // T scan workgroups + one that folds the extras
-    hipLaunchKernelGGL(anymal_scan_kernel, dim3((unsigned)T + 1), dim3(ANT), 0, st, a);
+    launch_anymal_scan(a, st);
     return check_launch("anymal_scan_kernel");
   }
   hipLaunchKernelGGL(anymal_extras_kernel, dim3(1), dim3(1024), 0, st, a);
