@@ -817,8 +817,13 @@ __device__ __forceinline__ void cursor_advance(int& e, int& k, int de, int dk, i
 // quarter of the 250 instructions of its loop -- and drew its noise behind the gathers' wait.  Same values, bit for bit:
 // 70.0 -> 66.4 us.  What else was tried (one lane per point for the gathers, resident workgroups fed by a queue or a fixed
 // stride, staggered starts) and what the ablations say: profiles/r03/anymal_scan_layout.txt, DESIGN.md 3.0.
+#ifdef OIGE_EXP_SCAN_STILE
+constexpr int STILE = OIGE_EXP_SCAN_STILE;
+constexpr int SNT = (STILE * 10 + WAVE - 1) / WAVE * WAVE;
+#else
 constexpr int STILE = 32;        // envs per scan workgroup
 constexpr int SNT = STILE * 10;  // 320 threads (5 waves): thread j = env j / 10, grid column j % 10
+#endif
 constexpr int SCD = 28;          // per-env LDS table: -(z ty)[14], (w ty)[14]
 __host__ __device__ inline int64_t scan_tiles(int64_t n) { return (n + STILE - 1) / STILE; }
 __host__ __device__ constexpr float scan_hx(int ix) { return 0.1f * (float)(ix < 7 ? ix - 8 : ix - 5); }  // :178-180
@@ -831,7 +836,8 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
   const uint64_t noise_step = step_of(a.r);
   const int64_t env0 = t * STILE;
   const float* pose_in = a.b.reduce_workspace + pose_offset(num_tiles(a.n)) + env0 * APOSE;
-  const int e = tid / 10, iy = tid - 10 * e;
+  // (a workgroup with spare lanes: they repeat the first columns of the tile's last env -- same values to the same places)
+  const int e = tid / 10 < STILE ? tid / 10 : STILE - 1, iy = tid < STILE * 10 ? tid - 10 * e : tid - STILE * 10;
   const int e_ld = e < nv ? e : nv - 1;  // lanes past a ragged tile's end repeat its last env; nothing of theirs is stored
 #ifdef OIGE_EXP_SCAN_YAW
   float4 q = *reinterpret_cast<const float4*>(pose_in + e_ld * APOSE);
@@ -857,7 +863,7 @@ __device__ __forceinline__ void anymal_scan_tile(const AnymalPost& a, float* __r
   int fe = tid / AP4, fk = tid - AP4 * fe;
   auto draw = [&](int ps) {
     gfs[ps] = __umul24((uint32_t)env0 + (uint32_t)fe, (uint32_t)(AO / 4)) + 9u + (uint32_t)fk;  // env < 2^23
-    const bool live = fe < nv && (ps * SNT + SNT <= F4 || ps * SNT + tid < F4);
+    const bool live = fe < nv && fe < STILE && (ps * SNT + SNT <= F4 || ps * SNT + tid < F4);
     if (!live) gfs[ps] = 0xffffffffu;
     nz[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifndef OIGE_EXP_NO_NOISE
@@ -986,6 +992,7 @@ __device__ __forceinline__ void anymal_extras_body(const AnymalPost& a, double (
   double acc[AE + 1];
 #pragma unroll
   for (int k = 0; k <= AE; ++k) acc[k] = 0.0;
+#pragma unroll 4
   for (int64_t i = threadIdx.x; i < T; i += NT) {
 #pragma unroll
     for (int k = 0; k <= AE; ++k) acc[k] += (double)a.b.reduce_workspace[i * RW + 1 + k];
@@ -1024,6 +1031,7 @@ __global__ __launch_bounds__(SNT) SCAN_OCC void anymal_scan_kernel(const AnymalP
   __shared__ __align__(16) float s_cd[STILE * SCD];
   if (blockIdx.x == 0) {
     static_assert(sizeof(double) * (SNT / WAVE) * (AE + 1) <= sizeof(float) * STILE * AP, "extras partials fit in s_out");
+    static_assert(SNT >= AE + 1, "one thread per extras entry");
     if (a.stages == 0) anymal_extras_body<SNT>(a, reinterpret_cast<double (*)[AE + 1]>(s_out));  // (get_observations alone resets nothing)
     return;
   }
