@@ -185,8 +185,8 @@ def test_replay_cost_at_the_reference_size():
     if os.path.isdir(d):
         with open(os.path.join(d, "graph_step_timing.json"), "w") as f:
             json.dump(out, f, indent=1)
-    for rec in out.values():   # a measurement, not a gate: only a gross regression fails (the boxes are shared, timings jitter)
-        assert rec["graph_replay_us_per_step"] < 2.0 * rec["eager_us_per_step"]
+    for rec in out.values():   # a measurement, not a gate: only a gross regression fails (the boxes are shared, timings jitter,
+        assert rec["graph_replay_us_per_step"] < 5.0 * rec["eager_us_per_step"]   # and the eager step is ~20 us of host work now)
 
 
 @pytest.mark.parametrize("cfg,n", [("ShadowHand", 700), ("AllegroHand", 300), ("Ant", 1000), ("FrankaCabinet", 500)])
