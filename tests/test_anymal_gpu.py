@@ -112,6 +112,44 @@ def test_post_physics_matches_oracle(n, noise):
     _compare(task, b, env_ids, view, n)
 
 
+@pytest.mark.parametrize("noise", ["philox", "off"])
+def test_height_scan_keeps_nan_and_infinite_base_heights(noise):
+    """heights = clip(z - 0.5 - measured, -1, 1) * scale (:537-539): torch.clip keeps a NaN and maps +-inf to +-1.  The scan kernel
+    takes the clip as one median instruction, which would return a bound for a NaN, and repairs NaN rows on a path of its own,
+    chosen per wave: envs with such a base height sit in the first, a middle and the last (ragged) workgroup here."""
+    n = 300
+    env, task = make_task("AnymalTerrain", n)
+    st = workloads.anymal_state(n, task.terrain_origins.cpu(), task.default_dof_pos.cpu(), device="cpu", seed=77)
+    nan, inf = float("nan"), float("inf")
+    for i, z in ((0, nan), (5, inf), (6, -inf), (63, nan), (64, nan), (130, inf), (131, nan), (288, nan), (299, -inf)):
+        st["base_pos"][i, 2] = z
+    workloads.load_anymal_state(task, st)
+    task._anymals.apply_resets = False
+    task.add_noise = noise != "off"
+    spec = _spec(task)
+    s, b = _oracle_inputs(task, st)
+    seed, step = task._rand_seed, task._step_count + 1
+    ao.post_physics(spec, b, s, task.height_samples.cpu(), task.terrain_origins.cpu(), draw=_philox_draws(seed, step),
+                    noise_u=_philox_noise(n, seed, step) if noise == "philox" else None)
+    task.post_physics_step()
+    torch.cuda.synchronize()
+    got, want = task.obs_buf.cpu(), b.obs_buf
+    # (an env that resets in this step is measured at its reset pose, :421-437: its heights are numbers again)
+    stay = ~b.reset_buf
+    nan_rows = [i for i in (0, 63, 64, 131, 288) if stay[i]]
+    inf_rows = [i for i in (5, 6, 130, 299) if stay[i]]
+    assert len(nan_rows) >= 3 and len(inf_rows) >= 2, "the seed keeps enough of the marked envs out of the reset"
+    assert want[nan_rows][:, 36:176].isnan().all(), "the oracle keeps NaN heights (scan columns 36:176)"
+    assert not want[inf_rows][:, 36:176].isnan().any()
+    if noise == "off":
+        assert (want[inf_rows][:, 36:176].abs() == spec.height_meas_scale).all()
+    assert_equal(got.isnan(), want.isnan(), "NaN pattern of obs_buf")
+    assert_close(torch.nan_to_num(got, nan=0.0), torch.nan_to_num(want, nan=0.0), "obs_buf where it is a number")
+    assert_equal(task.rew_buf.cpu().isnan(), b.rew_buf.isnan(), "NaN pattern of rew_buf")
+    assert_close(torch.nan_to_num(task.rew_buf.cpu(), nan=0.0), torch.nan_to_num(b.rew_buf, nan=0.0), "rew_buf where it is a number")
+    assert_equal(task.reset_buf, b.reset_buf, "reset_buf")
+
+
 def test_second_step_uses_the_reset_rows_and_new_draws():
     """Two steps in a row with the setters applied: the second step starts from the first one's reset rows."""
     n = 300
